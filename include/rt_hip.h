@@ -1,0 +1,200 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) ray-tracing library, librt_hip.so.
+ *
+ * The library is the GPU replacement for the per-pixel render loop of the
+ * reference CPU ray tracer: everything that runs per pixel after key 'r'.
+ * Each entry point names the reference interface it stands in for
+ * (file:line in the reference checkout).  All entry points return 0 on
+ * success or a negative RtError; rt_last_error() gives the message of the last
+ * failure on the calling thread.  No C++ exception crosses this boundary.
+ *
+ * Threading: calls on one RtScene are serialised by the caller.  Entry points
+ * without a stream argument are synchronous; the *_device entry points enqueue
+ * on the given HIP stream and return without waiting unless a stats pointer is
+ * passed.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum RtError {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument (null pointer, size out of range, bad index) */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    RT_ERR_UNSUPPORTED = -3, /* valid request the library cannot serve (tree too deep, ...) */
+    RT_ERR_NO_DEVICE = -4
+} RtError;
+
+#define RT_MAX_LIGHTS 64
+
+typedef struct RtScene RtScene;
+
+/* One material as the shading loop reads it (mesh.h:141-147, 170-178).
+ * has_Ni mirrors Material::has_Ni(); Ni carries the stored value even when
+ * has_Ni is 0 because raytracing.cpp:206 tests Ni() without the flag. */
+typedef struct RtMaterial {
+    float   Kd[3];
+    float   Ks[3];
+    float   Ns;
+    float   Ni;
+    int32_t illum;
+    int32_t has_Ni;
+    int32_t texture; /* index into RtSceneDesc.textures, -1 = hasTexture() false */
+    int32_t reserved[5];
+} RtMaterial;
+
+/* RGBA8 image, row major, top row first (corona::PF_R8G8B8A8, mesh.h:121).
+ * The library appends two rows of zero bytes: mesh.cpp:499 can index one row
+ * past the image. */
+typedef struct RtTexture {
+    const uint8_t *rgba;
+    int32_t        width, height;
+} RtTexture;
+
+/* One AccelTreeNode (KDtree.h:9-27) with pointers replaced by indices.
+ * Node 0 is treeRoot; left == right == -1 marks a leaf. */
+typedef struct RtKdNode {
+    float   bounds[6]; /* xStart xEnd yStart yEnd zStart zEnd */
+    int32_t left, right;
+    int32_t tri_offset, tri_count; /* range in RtSceneDesc.node_tris */
+} RtKdNode;
+
+/* The globals the reference's tracer reads (raytracing.h:12-21): MyMesh and
+ * treeRoot, flattened by the host. */
+typedef struct RtSceneDesc {
+    int32_t           n_vertices;
+    const float      *vertex_pos;    /* 3 per vertex: Vertex::p */
+    const float      *vertex_normal; /* 3 per vertex: Vertex::n after computeVertexNormals */
+    int32_t           n_triangles;
+    const int32_t    *tri_vertex;    /* 3 per triangle: Triangle::v */
+    const int32_t    *tri_texcoord;  /* 3 per triangle: Triangle::t */
+    const int32_t    *tri_material;  /* Mesh::triangleMaterials */
+    int32_t           n_texcoords;
+    const float      *texcoords;     /* 3 per entry (Vec3Df, z unused) */
+    int32_t           n_materials;
+    const RtMaterial *materials;
+    int32_t           n_textures;
+    const RtTexture  *textures;
+    int32_t           n_nodes;
+    const RtKdNode   *nodes;
+    int32_t           n_node_tris;
+    const int32_t    *node_tris;     /* concatenated AccelTreeNode::triangles */
+} RtSceneDesc;
+
+/* settings.h:7-19 and config.h's WindowSize as run-time values, plus the
+ * screen-space partition used when several GPUs share a frame. */
+typedef struct RtParams {
+    int32_t width, height;     /* WindowSize_X / WindowSize_Y */
+    int32_t msaa;              /* 1, 4 or 16 (settings.h:15) */
+    float   backgroundlighting; /* settings.h:7 */
+    float   diffusePower;      /* settings.h:8 */
+    float   ShadowFactor;      /* settings.h:10 */
+    float   depthPower;        /* settings.h:16 */
+    float   backgroundColor[3]; /* settings.h:18 */
+    float   focusDepth;        /* raytracing.cpp:17 */
+    /* Tiles of tile_w x tile_h pixels (multiples of 8) are dealt round-robin:
+     * this call renders tiles t with t % world == rank.  tile_w == 0 means
+     * the whole frame (rank 0 of 1). */
+    int32_t tile_w, tile_h;
+    int32_t rank, world;
+} RtParams;
+
+typedef struct RtStats {
+    uint64_t rays_closest; /* closest-hit queries traced on the GPU */
+    uint64_t rays_shadow;  /* shadow (any-hit) queries traced on the GPU */
+    uint64_t tri_tests;    /* ray/triangle tests executed */
+    uint64_t node_visits;  /* KD nodes visited */
+    uint64_t camera_rays;  /* camera samples evaluated (incl. centre visibility rays) */
+    float    kernel_ms;    /* HIP-event time of the call's kernels */
+    float    reserved;
+} RtStats;
+
+typedef struct RtSceneInfo {
+    int32_t  n_nodes, n_triangles, tree_depth, n_slots;
+    uint64_t device_bytes;
+} RtSceneInfo;
+
+/* RtParams with the reference's constants. */
+void rt_default_params(RtParams *p, int32_t width, int32_t height);
+
+int         rt_device_count(void);
+const char *rt_last_error(void);
+
+/* Takes over from the end of init() (raytracing.cpp:23-53): the mesh is
+ * loaded, normals computed, the KD tree built; this call lays both out for
+ * the GPU and uploads them to `device`.  The host arrays are not referenced
+ * after the call returns. */
+int  rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
+void rt_scene_destroy(RtScene *scene);
+int  rt_scene_info(const RtScene *scene, RtSceneInfo *info);
+
+/* checkHit(origin, dest, minT) (raytracing.h:77, raytracing.cpp:281-351) for n
+ * rays.  tri is the index into Mesh::triangles of the closest hit, -1 for a
+ * miss; a, b, t, hitpoint as HitTriangle/minT.  Any output may be NULL. */
+int rt_check_hits(RtScene *scene, int64_t n, const float *origins, const float *dests,
+                  int32_t *tri, float *a, float *b, float *t, float *hitpoint);
+
+/* performRayTracing(origin, dest, k, prev_Ni, minT) (raytracing.h:33,
+ * raytracing.cpp:61-274) for n rays sharing k (0..5) and prev_Ni; the frame
+ * driver calls it with k = 0, prev_Ni = 1.0f (main.cpp:528).  rgb is the
+ * returned Vec3Df (unclamped), min_t the depth of the first hit (FLT_MAX on a
+ * miss), tri its triangle. */
+int rt_trace_rays(RtScene *scene, const float *lights, int32_t n_lights, const RtParams *params,
+                  int32_t k, float prev_Ni, int64_t n, const float *origins, const float *dests,
+                  float *rgb, float *min_t, int32_t *tri, RtStats *stats);
+
+/* One frame of the 'r' path: RayTracer::threadmethod over every pixel
+ * (main.cpp:391-408) = raytraceMSAA (main.cpp:435-511) + Image::setPixel with
+ * the RGBValue clamp (imageWriter.h:23-44, 99-105).  camera = the eight corner
+ * points of main.cpp:52-55 in the order origin00 dest00 origin01 dest01
+ * origin10 dest10 origin11 dest11.  Outputs are width*height, row major:
+ * rgb 3 floats per pixel, depth 1 float, tri (may be NULL) the triangle hit by
+ * the pixel-centre ray.  Host pointers. */
+int rt_render_frame(RtScene *scene, const float camera[24], const float *lights, int32_t n_lights,
+                    const RtParams *params, float *rgb, float *depth, int32_t *tri,
+                    RtStats *stats);
+
+/* Same with device pointers on the scene's device, enqueued on `stream`
+ * (a hipStream_t).  Pixels outside this rank's tiles are not written.  With
+ * stats != NULL the call waits for completion and fills it. */
+int rt_render_frame_device(RtScene *scene, const float camera[24], const float *lights,
+                           int32_t n_lights, const RtParams *params, float *d_rgb, float *d_depth,
+                           int32_t *d_tri, void *stream, RtStats *stats);
+
+/* Image::normailzeDepthRange (imageWriter.h:113-135), in place, n values. */
+int rt_normalize_depth(int device, int64_t n, float focus_depth, float *depth);
+int rt_normalize_depth_device(int device, int64_t n, float focus_depth, float *d_depth,
+                              void *stream);
+
+/* Image::blurrAllLines (imageWriter.h:137-237): depth-dependent 13x13 blur of
+ * the float image; depth_n is the normalised depth.  out is
+ * (width-12)*(height-12)*3 floats. */
+int rt_dof_blur(int device, int32_t width, int32_t height, float depth_power, const float *rgb,
+                const float *depth_n, float *out);
+int rt_dof_blur_device(int device, int32_t width, int32_t height, float depth_power,
+                       const float *d_rgb, const float *d_depth_n, float *d_out, void *stream);
+
+/* (unsigned char)(v * 255.0f) of imageWriter.h:270,322-324 for n floats. */
+int rt_quantize(int device, int64_t n, const float *v, uint8_t *out);
+
+/* Screen-space partition helpers.  They replace the row bands of
+ * main.cpp:329-339 when a frame is shared by `world` GPUs.
+ * rt_tile_pixels: number of pixel slots (whole tiles) rank owns.
+ * rt_pack_tiles_device: copy the rank's tiles of the frame buffers into a
+ *   payload of rt_tile_pixels * 4 floats (r g b depth per pixel slot).
+ * rt_unpack_tiles_device: the inverse, for the tiles of `src_rank`. */
+int64_t rt_tile_pixels(const RtParams *params, int32_t rank);
+int     rt_pack_tiles_device(int device, const RtParams *params, const float *d_rgb,
+                             const float *d_depth, float *d_payload, void *stream);
+int     rt_unpack_tiles_device(int device, const RtParams *params, int32_t src_rank,
+                               const float *d_payload, float *d_rgb, float *d_depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -979,7 +979,7 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
             if (c) c->rays_shadow++;
             if (sh.bHit) shadowMax = 1.f;
         }
-        shadowMax = shadowMax > softShadow ? shadowMax : softShadow; /* std::max(shadowMax, softShadow) */
+        shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax; /* std::max(shadowMax, softShadow) */
         resCol = vsub(resCol, vscale(shadowRGB, shadowMax));
     }
 

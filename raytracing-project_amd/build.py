@@ -1,0 +1,70 @@
+"""Builds the package's native libraries in-tree with hipcc / g++.
+
+  csrc/librt_hip.so   - HIP kernels + the C ABI of include/rt_hip.h (gfx950)
+  csrc/librt_host.so  - C++ host side (scene loader, KD build, camera, image
+                        writers, the raytracing.h-style surface); links to
+                        librt_hip.so
+  csrc/rt_render      - headless command line front end of the 'r' render path
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+              "-I" + os.path.join(ROOT, "include")]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def build_hip(force=False):
+    out = os.path.join(CSRC, "librt_hip.so")
+    src = [os.path.join(CSRC, "rt_api.hip"), os.path.join(CSRC, "rt_device.h"),
+           os.path.join(ROOT, "include", "rt_hip.h")]
+    if force or _newer(out, src):
+        subprocess.check_call([hipcc(), *HIP_FLAGS, "-shared", src[0], "-o", out])
+    return out
+
+
+def build_host(force=False):
+    out = os.path.join(CSRC, "librt_host.so")
+    hdir = os.path.join(CSRC, "host")
+    src = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp")
+                 and f != "rt_render_main.cpp")
+    deps = src + [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".hpp")]
+    if force or _newer(out, deps + [os.path.join(CSRC, "librt_hip.so")]):
+        subprocess.check_call(["g++", *HOST_FLAGS, "-shared", *src, "-o", out,
+                               "-L" + CSRC, "-lrt_hip", "-lz", "-lpthread",
+                               "-Wl,-rpath,$ORIGIN"])
+    cli = os.path.join(CSRC, "rt_render")
+    main = os.path.join(hdir, "rt_render_main.cpp")
+    if os.path.exists(main) and (force or _newer(cli, [main, out])):
+        subprocess.check_call(["g++", *HOST_FLAGS, main, "-o", cli, "-L" + CSRC, "-lrt_host",
+                               "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_all(force=False):
+    build_hip(force)
+    if os.path.isdir(os.path.join(CSRC, "host")):
+        build_host(force)
+
+
+if __name__ == "__main__":
+    build_all(force=True)

@@ -1,0 +1,1013 @@
+// rt_api.hip - kernels and the extern "C" layer of librt_hip.so (see
+// include/rt_hip.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" const char* rt_last_error(void) { return g_err; }
+
+extern "C" int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void rt_default_params(RtParams* p, int32_t width, int32_t height)
+{
+    memset(p, 0, sizeof *p);
+    p->width = width, p->height = height;
+    p->msaa = 1;
+    p->backgroundlighting = 0.34f;
+    p->diffusePower = 0.5f;
+    p->ShadowFactor = 0.5f;
+    p->depthPower = 2.5f;
+    p->backgroundColor[0] = 0.2f, p->backgroundColor[1] = 0.5f, p->backgroundColor[2] = 1.0f;
+    p->focusDepth = 0.0f;
+    p->tile_w = p->tile_h = 0;
+    p->rank = 0, p->world = 1;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+#define RT_BLOCK 256
+
+__device__ __forceinline__ void flush_counters(DCounters* ctr, unsigned nc, unsigned ns, unsigned nt,
+                                               unsigned nn, unsigned ncam)
+{
+    // one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) {
+        nc += __shfl_down(nc, off);
+        ns += __shfl_down(ns, off);
+        nt += __shfl_down(nt, off);
+        nn += __shfl_down(nn, off);
+        ncam += __shfl_down(ncam, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr->rays_closest, (unsigned long long)nc);
+        atomicAdd(&ctr->rays_shadow, (unsigned long long)ns);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)nt);
+        atomicAdd(&ctr->node_visits, (unsigned long long)nn);
+        atomicAdd(&ctr->camera_rays, (unsigned long long)ncam);
+    }
+}
+
+__device__ __forceinline__ float clamp01(float v) // imageWriter.h:26-44
+{
+    if (v > 1.0f) v = 1.0f;
+    if (v < 0.0f) v = 0.0f;
+    return v;
+}
+
+// checkHit for a batch of rays
+__global__ void __launch_bounds__(RT_BLOCK)
+k_check_hits(DScene S, long long n, const float* __restrict__ org, const float* __restrict__ dst,
+             int* tri, float* a, float* b, float* t, float* hp, DCounters* ctr)
+{
+    extern __shared__ uint2 s_stack[];
+    const long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    unsigned        nt = 0, nn = 0, nc = 0;
+    if (i < n) {
+        const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        const f3 d = mk3(dst[3 * i], dst[3 * i + 1], dst[3 * i + 2]);
+        HitRec   h;
+        nc = 1;
+        const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
+        if (tri) tri[i] = got ? __float_as_int(S.tris[3 * h.slot + 2].w) : -1;
+        if (a) a[i] = h.a;
+        if (b) b[i] = h.b;
+        if (t) t[i] = h.t;
+        if (hp) {
+            const f3 p = got ? o + (d - o) * h.t : mk3(0.0f, 0.0f, 0.0f);
+            hp[3 * i] = p.x, hp[3 * i + 1] = p.y, hp[3 * i + 2] = p.z;
+        }
+    }
+    flush_counters(ctr, nc, 0, nt, nn, 0);
+}
+
+// performRayTracing for a batch of rays
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace_rays(DScene S, DParams P, int k0, float prev_ni, long long n, const float* __restrict__ org,
+             const float* __restrict__ dst, float* rgb, float* minT, int* tri, DCounters* ctr)
+{
+    extern __shared__ uint2 s_stack[];
+    const long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    if (i < n) {
+        const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        const f3 d = mk3(dst[3 * i], dst[3 * i + 1], dst[3 * i + 2]);
+        f3       c;
+        float    mt;
+        int      ft;
+        ncam = 1;
+        trace_sample(S, P, o, d, k0, prev_ni, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+        rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+        if (minT) minT[i] = mt;
+        if (tri) tri[i] = ft;
+    }
+    flush_counters(ctr, nc, ns, nt, nn, ncam);
+}
+
+// Pixel-centre ray of every pixel slot.  MSAA == 1: the whole sample, pixel
+// written.  MSAA > 1: visibility only (main.cpp:440-445 needs just hit/miss of
+// the centre ray; its colour is discarded at main.cpp:452); missed pixels are
+// final, hit pixels are flagged for k_samples.
+template <bool FULL>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* tri,
+         unsigned char* hit_flag, DCounters* ctr)
+{
+    extern __shared__ uint2 s_stack[];
+    const long long slot = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    int             x, y;
+    if (slot < n_slots && slot_to_pixel(P, slot, x, y)) {
+        f3 o, d;
+        pixel_ray(P, (double)x, (double)y, o, d);
+        const size_t p = (size_t)y * P.W + x;
+        ncam = 1;
+        if (FULL) {
+            f3    c;
+            float mt;
+            int   ft;
+            trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+            rgb[3 * p] = clamp01(c.x), rgb[3 * p + 1] = clamp01(c.y), rgb[3 * p + 2] = clamp01(c.z);
+            depth[p] = mt; // FLT_MAX on a miss (main.cpp:442-443)
+            if (tri) tri[p] = ft;
+        } else {
+            HitRec h;
+            nc = 1;
+            const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
+            if (tri) tri[p] = got ? __float_as_int(S.tris[3 * h.slot + 2].w) : -1;
+            hit_flag[slot] = got ? 1 : 0;
+            if (!got) {
+                rgb[3 * p] = clamp01(P.bg[0]), rgb[3 * p + 1] = clamp01(P.bg[1]),
+                        rgb[3 * p + 2] = clamp01(P.bg[2]);
+                depth[p] = RT_FLT_MAX;
+            }
+        }
+    }
+    flush_counters(ctr, nc, ns, nt, nn, ncam);
+}
+
+__constant__ float c_msaa4[4][2] = {{-1.f / 8, -3.f / 8}, {3.f / 8, -1.f / 8}, {-3.f / 8, 1.f / 8},
+                                    {1.f / 8, 3.f / 8}}; // main.cpp:452-458
+__constant__ float c_msaa16[16][2] = {
+    {-9.f / 32, -15.f / 32}, {-1.f / 32, -13.f / 32}, {7.f / 32, -11.f / 32}, {15.f / 32, -9.f / 32},
+    {-11.f / 32, -7.f / 32}, {-3.f / 32, -5.f / 32},  {5.f / 32, -3.f / 32},  {13.f / 32, -1.f / 32},
+    {-13.f / 32, 1.f / 32},  {-5.f / 32, 3.f / 32},   {3.f / 32, 5.f / 32},   {11.f / 32, 7.f / 32},
+    {-15.f / 32, 9.f / 32},  {-7.f / 32, 11.f / 32},  {1.f / 32, 13.f / 32},  {9.f / 32, 15.f / 32}};
+// main.cpp:469-500 (all offsets are exact binary fractions)
+
+// One thread per (sample, pixel slot) of the pixels whose centre ray hit.
+// samples[(slot * msaa + s)] = r g b minT.
+__global__ void __launch_bounds__(RT_BLOCK)
+k_samples(DScene S, DParams P, long long n_slots, const unsigned char* __restrict__ hit_flag,
+          float4* samples, DCounters* ctr)
+{
+    extern __shared__ uint2 s_stack[];
+    const long long idx = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const int       s = (int)(idx / n_slots);
+    const long long slot = idx - (long long)s * n_slots;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    int             x, y;
+    if (s < P.msaa && hit_flag[slot] && slot_to_pixel(P, slot, x, y)) {
+        const float ox = P.msaa == 4 ? c_msaa4[s][0] : c_msaa16[s][0];
+        const float oy = P.msaa == 4 ? c_msaa4[s][1] : c_msaa16[s][1];
+        f3          o, d, c;
+        pixel_ray(P, (double)x + (double)ox, (double)y + (double)oy, o, d);
+        float mt;
+        int   ft;
+        ncam = 1;
+        trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+        samples[slot * P.msaa + s] = make_float4(c.x, c.y, c.z, mt);
+    }
+    flush_counters(ctr, nc, ns, nt, nn, ncam);
+}
+
+// main.cpp:449-507: ordered sum of the samples, divided by their number;
+// depth = mean of minT over the samples that hit.
+__global__ void k_resolve(DParams P, long long n_slots, const unsigned char* __restrict__ hit_flag,
+                          const float4* __restrict__ samples, float* rgb, float* depth)
+{
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int             x, y;
+    if (slot >= n_slots || !hit_flag[slot] || !slot_to_pixel(P, slot, x, y)) return;
+    float r = 0, g = 0, b = 0, dsum = 0;
+    int   hits = 0;
+    for (int s = 0; s < P.msaa; ++s) {
+        const float4 v = samples[slot * P.msaa + s];
+        if (s == 0) r = v.x, g = v.y, b = v.z;
+        else r += v.x, g += v.y, b += v.z;
+        if (v.w != RT_FLT_MAX) dsum += v.w, ++hits;
+    }
+    const float  n = (float)P.msaa;
+    const size_t p = (size_t)y * P.W + x;
+    rgb[3 * p] = clamp01(__fdiv_rn(r, n));
+    rgb[3 * p + 1] = clamp01(__fdiv_rn(g, n));
+    rgb[3 * p + 2] = clamp01(__fdiv_rn(b, n));
+    depth[p] = hits > 0 ? __fdiv_rn(dsum, (float)hits) : RT_FLT_MAX;
+}
+
+// ---- depth range, imageWriter.h:113-122 ----
+__global__ void k_depth_range_partial(const float* __restrict__ depth, long long n, float* part_lo,
+                                      float* part_hi)
+{
+    __shared__ float s_lo[256], s_hi[256];
+    float            lo = RT_FLT_MAX, hi = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float v = depth[i];
+        lo = fminf(lo, v);
+        if (v != RT_FLT_MAX) hi = fmaxf(hi, v);
+    }
+    s_lo[threadIdx.x] = lo, s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
+            s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_lo[blockIdx.x] = s_lo[0], part_hi[blockIdx.x] = s_hi[0];
+}
+
+// imageWriter.h:124-135; one block reduces the partials, every block normalises
+__global__ void k_depth_normalize(float* depth, long long n, const float* __restrict__ part_lo,
+                                  const float* __restrict__ part_hi, int n_part, float focus)
+{
+    __shared__ float s_denom;
+    if (threadIdx.x == 0) {
+        float lo = RT_FLT_MAX, hi = 0.0f;
+        for (int i = 0; i < n_part; ++i) lo = fminf(lo, part_lo[i]), hi = fmaxf(hi, part_hi[i]);
+        s_denom = fmaxf(fabsf(lo - focus), fabsf(hi - focus));
+    }
+    __syncthreads();
+    const float denom = s_denom;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float v = depth[i];
+        depth[i] = (v != RT_FLT_MAX) ? __fdiv_rn(fabsf(v - focus), denom) : 0.0f;
+    }
+}
+
+// ---- depth-of-field blur, imageWriter.h:137-231 ----
+// The 13x13 kernel of a pixel depends on (i-6)^2 + (j-6)^2 only through
+// -((..)/2) with integer division, i.e. 37 possible exponents; each thread
+// evaluates those powf once (table in LDS), then walks the 169 taps in the
+// reference's order for both the normalisation sum and the gather.
+#define DOF_BLOCK 128
+__global__ void __launch_bounds__(DOF_BLOCK)
+k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int W, int H,
+           float depthPower, float* out)
+{
+    __shared__ float s_tab[37 * DOF_BLOCK];
+    const int        bw = W - 12, bh = H - 12;
+    const long long  idx = (long long)blockIdx.x * DOF_BLOCK + threadIdx.x;
+    if (idx >= (long long)bw * bh) return;
+    const int ox = (int)(idx % bw), oy = (int)(idx / bw);
+    const int cx = ox + 6, cy = oy + 6;
+    float     I = 1.0f - depthN[(size_t)cy * W + cx];
+    I *= I;
+    float* o = out + 3 * idx;
+    if (I >= 1.0f) { // identity kernel
+        const float* p = rgb + 3 * ((size_t)cy * W + cx);
+        o[0] = p[0], o[1] = p[1], o[2] = p[2];
+        return;
+    }
+    float*       tab = s_tab + threadIdx.x;
+    const float  idp = I * depthPower;
+    const float  p2 = powf(idp, 2.0f);
+    const double c1 = 1.0 / ((double)(idp * 2.0f) * 3.14159265358979323846);
+    const float  e = (float)2.71828182845904523536;
+    for (int k = 0; k < 37; ++k)
+        tab[k * DOF_BLOCK] = (float)(c1 * (double)powf(e, (float)(-k) * p2));
+    float total = 0.0f;
+    for (int i = 0; i < 13; ++i)
+        for (int j = 0; j < 13; ++j)
+            total += tab[(((i - 6) * (i - 6) + (j - 6) * (j - 6)) >> 1) * DOF_BLOCK];
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int j = 0; j < 13; ++j)
+        for (int k = 0; k < 13; ++k) {
+            const float  w = __fdiv_rn(tab[(((j - 6) * (j - 6) + (k - 6) * (k - 6)) >> 1) * DOF_BLOCK], total);
+            const float* p = rgb + 3 * ((size_t)(cy + j - 6) * W + cx + k - 6);
+            r += p[0] * w;
+            g += p[1] * w;
+            b += p[2] * w;
+        }
+    o[0] = r, o[1] = g, o[2] = b;
+}
+
+// (unsigned char)(v * 255.0f) with NaN and out-of-int-range -> 0 (what x86
+// cvttss2si + truncation to a byte gives)
+__global__ void k_quantize(const float* __restrict__ v, long long n, unsigned char* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = v[i] * 255.0f;
+    int         q = 0;
+    if (x == x && x < 2147483648.0f && x >= -2147483648.0f) q = (int)x;
+    out[i] = (unsigned char)q;
+}
+
+__global__ void k_pack_tiles(DParams P, long long n_slots, const float* __restrict__ rgb,
+                             const float* __restrict__ depth, float4* payload)
+{
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    int    x, y;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (slot_to_pixel(P, slot, x, y)) {
+        const size_t p = (size_t)y * P.W + x;
+        v = make_float4(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], depth[p]);
+    }
+    payload[slot] = v;
+}
+
+__global__ void k_unpack_tiles(DParams P, long long n_slots, const float4* __restrict__ payload,
+                               float* rgb, float* depth)
+{
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    int x, y;
+    if (!slot_to_pixel(P, slot, x, y)) return;
+    const float4 v = payload[slot];
+    const size_t p = (size_t)y * P.W + x;
+    rgb[3 * p] = v.x, rgb[3 * p + 1] = v.y, rgb[3 * p + 2] = v.z;
+    depth[p] = v.w;
+}
+
+// ---------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------
+struct RtScene {
+    int     device = 0;
+    DScene  d{};
+    void*   d_nodes = nullptr;
+    void*   d_tris = nullptr;
+    void*   d_shade = nullptr;
+    void*   d_info = nullptr;
+    void*   d_texcoords = nullptr;
+    void*   d_mats = nullptr;
+    void*   d_texinfo = nullptr;
+    void*   d_texels = nullptr;
+    int     tree_depth = 0;
+    size_t  bytes = 0;
+    // per-call workspace, grown on demand
+    DCounters*     d_ctr = nullptr;
+    unsigned char* d_flags = nullptr;
+    size_t         flags_cap = 0;
+    float4*        d_samples = nullptr;
+    size_t         samples_cap = 0;
+    hipEvent_t     ev0 = nullptr, ev1 = nullptr;
+};
+
+template <class T>
+static int upload(void** dptr, const std::vector<T>& v, size_t* total)
+{
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 64);
+    HIP_TRY(hipMalloc(dptr, bytes));
+    HIP_TRY(hipMemset(*dptr, 0, bytes));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *total += bytes;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(RtScene* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out)
+{
+    if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    *out = nullptr;
+    const int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
+    if (device < 0 || device >= ndev)
+        return fail(RT_ERR_INVALID, "rt_scene_create: device %d out of range (0..%d)", device, ndev - 1);
+    const int nv = desc->n_vertices, nt = desc->n_triangles, nn = desc->n_nodes,
+              nm = desc->n_materials, ntc = desc->n_texcoords, ntex = desc->n_textures,
+              nnt = desc->n_node_tris;
+    if (nv < 0 || nt < 0 || nn < 0 || nm < 0 || ntc < 0 || ntex < 0 || nnt < 0)
+        return fail(RT_ERR_INVALID, "rt_scene_create: negative count");
+    if ((nv && (!desc->vertex_pos || !desc->vertex_normal)) ||
+        (nt && (!desc->tri_vertex || !desc->tri_material)) || (nm && !desc->materials) ||
+        (nn && !desc->nodes) || (nnt && !desc->node_tris) || (ntc && !desc->texcoords) ||
+        (ntex && !desc->textures))
+        return fail(RT_ERR_INVALID, "rt_scene_create: null array with non-zero count");
+    if (nt && nm == 0) return fail(RT_ERR_INVALID, "rt_scene_create: triangles but no materials");
+    if (nt >= (1 << 28)) return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many triangles");
+    for (int i = 0; i < nt; ++i) {
+        for (int j = 0; j < 3; ++j)
+            if (desc->tri_vertex[3 * i + j] < 0 || desc->tri_vertex[3 * i + j] >= nv)
+                return fail(RT_ERR_INVALID, "rt_scene_create: triangle %d vertex index out of range", i);
+        if (desc->tri_material[i] < 0 || desc->tri_material[i] >= nm)
+            return fail(RT_ERR_INVALID, "rt_scene_create: triangle %d material out of range", i);
+    }
+    for (int i = 0; i < nm; ++i)
+        if (desc->materials[i].texture >= ntex)
+            return fail(RT_ERR_INVALID, "rt_scene_create: material %d texture out of range", i);
+    for (int i = 0; i < ntex; ++i)
+        if (!desc->textures[i].rgba || desc->textures[i].width <= 0 || desc->textures[i].height <= 0)
+            return fail(RT_ERR_INVALID, "rt_scene_create: texture %d empty", i);
+
+    // ---- breadth-first relabelling of the tree, children adjacent ----
+    std::vector<int> order, depth_of;
+    std::vector<int> new_left; // by new index
+    std::vector<char> seen((size_t)nn, 0);
+    int               max_depth = 0;
+    if (nn > 0) {
+        order.push_back(0);
+        depth_of.push_back(0);
+        seen[0] = 1;
+        for (size_t head = 0; head < order.size(); ++head) {
+            const RtKdNode& n = desc->nodes[order[head]];
+            const bool      leaf = n.left < 0 && n.right < 0;
+            if (!leaf) {
+                if (n.left < 0 || n.right < 0 || n.left >= nn || n.right >= nn || seen[n.left] ||
+                    seen[n.right] || n.left == n.right)
+                    return fail(RT_ERR_INVALID, "rt_scene_create: node %d has bad children", order[head]);
+                seen[n.left] = seen[n.right] = 1;
+                new_left.push_back((int)order.size());
+                order.push_back(n.left);
+                order.push_back(n.right);
+                depth_of.push_back(depth_of[head] + 1);
+                depth_of.push_back(depth_of[head] + 1);
+                max_depth = std::max(max_depth, depth_of[head] + 1);
+            } else {
+                new_left.push_back(-1);
+            }
+            if (n.tri_count < 0 || n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > nnt)
+                return fail(RT_ERR_INVALID, "rt_scene_create: node %d triangle range out of bounds",
+                            order[head]);
+        }
+    }
+    if (max_depth + 1 > 64)
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: KD tree depth %d exceeds 63", max_depth);
+
+    std::vector<DNode>  nodes(order.size());
+    std::vector<float4> slots;
+    slots.reserve((size_t)nnt * 3);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const RtKdNode& n = desc->nodes[order[k]];
+        DNode           dn;
+        const int       axis = depth_of[k] % 3; // KDtree.cpp:75-133 cycles x,y,z with depth
+        dn.left = new_left[k];
+        dn.split = dn.left >= 0 ? desc->nodes[n.left].bounds[2 * axis + 1] : 0.0f;
+        dn.tri_off = (int)(slots.size() / 3);
+        dn.cnt_axis = n.tri_count | (axis << 28);
+        for (int i = 0; i < n.tri_count; ++i) {
+            const int t = desc->node_tris[n.tri_offset + i];
+            if (t < 0 || t >= nt)
+                return fail(RT_ERR_INVALID, "rt_scene_create: node %d lists triangle %d", order[k], t);
+            const float* v0 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t];
+            const float* v1 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t + 1];
+            const float* v2 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t + 2];
+            // separately rounded, exactly what raytracing.cpp:366-368 computes per test
+            volatile float e1x = v0[0] - v2[0], e1y = v0[1] - v2[1], e1z = v0[2] - v2[2];
+            volatile float e2x = v1[0] - v2[0], e2y = v1[1] - v2[1], e2z = v1[2] - v2[2];
+            volatile float p1 = e1x * e2y, p4 = e1z * e2y;
+            float          idx;
+            memcpy(&idx, &t, 4);
+            slots.push_back(make_float4(e1x, e1y, e1z, e2x));
+            slots.push_back(make_float4(e2y, e2z, v2[0], v2[1]));
+            slots.push_back(make_float4(v2[2], p1, p4, idx));
+        }
+        nodes[k] = dn;
+    }
+
+    std::vector<float4> shade((size_t)nt * 3);
+    std::vector<int4>   info((size_t)nt);
+    for (int t = 0; t < nt; ++t) {
+        for (int j = 0; j < 3; ++j) {
+            const float* nrm = desc->vertex_normal + 3 * desc->tri_vertex[3 * t + j];
+            shade[3 * t + j] = make_float4(nrm[0], nrm[1], nrm[2], 0.0f);
+        }
+        int tc[3] = {0, 0, 0};
+        for (int j = 0; j < 3; ++j) {
+            const int v = desc->tri_texcoord ? desc->tri_texcoord[3 * t + j] : 0;
+            tc[j] = (v >= 0 && v < ntc) ? v : 0;
+        }
+        info[t] = make_int4(desc->tri_material[t], tc[0], tc[1], tc[2]);
+    }
+    std::vector<float> texcoords((size_t)std::max(ntc, 1) * 3, 0.0f);
+    if (ntc) memcpy(texcoords.data(), desc->texcoords, sizeof(float) * 3 * (size_t)ntc);
+    std::vector<float4> mats((size_t)nm * 4);
+    for (int i = 0; i < nm; ++i) {
+        const RtMaterial& m = desc->materials[i];
+        float             fi, fh, ft;
+        const int32_t     tex = m.texture < 0 ? -1 : m.texture;
+        memcpy(&fi, &m.illum, 4), memcpy(&fh, &m.has_Ni, 4), memcpy(&ft, &tex, 4);
+        mats[4 * i] = make_float4(m.Kd[0], m.Kd[1], m.Kd[2], m.Ns);
+        mats[4 * i + 1] = make_float4(m.Ks[0], m.Ks[1], m.Ks[2], m.Ni);
+        mats[4 * i + 2] = make_float4(fi, fh, ft, 0.0f);
+        mats[4 * i + 3] = make_float4(0, 0, 0, 0);
+    }
+    std::vector<int4>    texinfo((size_t)std::max(ntex, 1), make_int4(0, 1, 1, 0));
+    std::vector<uint8_t> texels;
+    for (int i = 0; i < ntex; ++i) {
+        const RtTexture& t = desc->textures[i];
+        const size_t     body = (size_t)t.width * t.height * 4, pad = (size_t)t.width * 2 * 4;
+        if (texels.size() + body + pad > 0x7fffffffu)
+            return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: textures exceed 2 GiB");
+        texinfo[i] = make_int4((int)texels.size(), t.width, t.height, 0);
+        texels.insert(texels.end(), t.rgba, t.rgba + body);
+        texels.insert(texels.end(), pad, (uint8_t)0);
+    }
+    if (texels.empty()) texels.assign(64, 0);
+
+    HIP_TRY(hipSetDevice(device));
+    RtScene* s = new RtScene();
+    s->device = device;
+    s->tree_depth = max_depth;
+    int rc;
+    if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) ||
+        (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
+        (rc = upload(&s->d_texcoords, texcoords, &s->bytes)) ||
+        (rc = upload(&s->d_mats, mats, &s->bytes)) || (rc = upload(&s->d_texinfo, texinfo, &s->bytes)) ||
+        (rc = upload(&s->d_texels, texels, &s->bytes))) {
+        rt_scene_destroy(s);
+        return rc;
+    }
+    hipError_t e = hipMalloc((void**)&s->d_ctr, sizeof(DCounters));
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e != hipSuccess) {
+        rt_scene_destroy(s);
+        return fail(RT_ERR_HIP, "rt_scene_create: %s", hipGetErrorString(e));
+    }
+    s->d.nodes = (const DNode*)s->d_nodes;
+    s->d.tris = (const float4*)s->d_tris;
+    s->d.tri_shade = (const float4*)s->d_shade;
+    s->d.tri_info = (const int4*)s->d_info;
+    s->d.texcoords = (const float*)s->d_texcoords;
+    s->d.mats = (const float4*)s->d_mats;
+    s->d.tex_info = (const int4*)s->d_texinfo;
+    s->d.texels = (const uint8_t*)s->d_texels;
+    s->d.n_nodes = (int)nodes.size();
+    s->d.n_slots = (int)(slots.size() / 3);
+    s->d.n_triangles = nt;
+    s->d.stack_entries = max_depth + 1;
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_info(const RtScene* s, RtSceneInfo* info)
+{
+    if (!s || !info) return fail(RT_ERR_INVALID, "rt_scene_info: null argument");
+    info->n_nodes = s->d.n_nodes;
+    info->n_triangles = s->d.n_triangles;
+    info->tree_depth = s->tree_depth;
+    info->n_slots = s->d.n_slots;
+    info->device_bytes = s->bytes;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------
+static size_t stack_bytes(const RtScene* s) { return (size_t)s->d.stack_entries * RT_BLOCK * sizeof(uint2); }
+
+static int make_dparams(const RtParams* p, const float* camera, const float* lights, int n_lights,
+                        DParams* d)
+{
+    if (!p) return fail(RT_ERR_INVALID, "null params");
+    if (n_lights < 0 || n_lights > RT_MAX_LIGHTS)
+        return fail(RT_ERR_INVALID, "n_lights %d out of range (0..%d)", n_lights, RT_MAX_LIGHTS);
+    if (n_lights && !lights) return fail(RT_ERR_INVALID, "null lights");
+    if (p->msaa != 1 && p->msaa != 4 && p->msaa != 16)
+        return fail(RT_ERR_INVALID, "msaa must be 1, 4 or 16 (got %d)", p->msaa);
+    memset(d, 0, sizeof *d);
+    d->W = p->width, d->H = p->height, d->msaa = p->msaa, d->n_lights = n_lights;
+    d->backgroundlighting = p->backgroundlighting;
+    d->diffusePower = p->diffusePower;
+    d->ShadowFactor = p->ShadowFactor;
+    memcpy(d->bg, p->backgroundColor, 12);
+    if (camera) memcpy(d->cam, camera, sizeof d->cam);
+    if (n_lights) memcpy(d->lights, lights, sizeof(float) * 3 * (size_t)n_lights);
+    return RT_OK;
+}
+
+static int set_partition(const RtParams* p, int rank, DParams* d)
+{
+    if (p->width < 2 || p->height < 2 || p->width > 32768 || p->height > 32768)
+        return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", p->width, p->height);
+    int tw = p->tile_w, th = p->tile_h, world = p->world;
+    if (tw == 0 && th == 0) {
+        tw = th = 32;
+        world = 1;
+        rank = 0;
+    }
+    if (tw < 8 || th < 8 || (tw & 7) || (th & 7) || tw > 1024 || th > 1024)
+        return fail(RT_ERR_INVALID, "tile size %dx%d must be multiples of 8 in 8..1024", tw, th);
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(RT_ERR_INVALID, "rank %d / world %d invalid", rank, world);
+    d->tile_w = tw, d->tile_h = th, d->rank = rank, d->world = world;
+    d->tiles_x = (p->width + tw - 1) / tw;
+    d->tiles_y = (p->height + th - 1) / th;
+    const long long n_tiles = (long long)d->tiles_x * d->tiles_y;
+    d->n_my_tiles = (int)((n_tiles - rank + world - 1) / world);
+    if (d->n_my_tiles < 0) d->n_my_tiles = 0;
+    return RT_OK;
+}
+
+extern "C" int64_t rt_tile_pixels(const RtParams* params, int32_t rank)
+{
+    DParams d;
+    memset(&d, 0, sizeof d);
+    if (!params || set_partition(params, rank, &d) != RT_OK) return -1;
+    return (int64_t)d.n_my_tiles * d.tile_w * d.tile_h;
+}
+
+static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
+{
+    DCounters c;
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(&c, s->d_ctr, sizeof c, hipMemcpyDeviceToHost);
+    st->rays_closest = c.rays_closest;
+    st->rays_shadow = c.rays_shadow;
+    st->tri_tests = c.tri_tests;
+    st->node_visits = c.node_visits;
+    st->camera_rays = c.camera_rays;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
+    st->kernel_ms = ms;
+    st->reserved = 0;
+}
+
+static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// ---------------------------------------------------------------------------
+// batched rays
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return RT_OK;
+    }
+};
+
+extern "C" int rt_check_hits(RtScene* s, int64_t n, const float* origins, const float* dests,
+                             int32_t* tri, float* a, float* b, float* t, float* hitpoint)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_check_hits: null scene");
+    if (n < 0 || n > (int64_t)1 << 31) return fail(RT_ERR_INVALID, "rt_check_hits: n out of range");
+    if (n == 0) return RT_OK;
+    if (!origins || !dests) return fail(RT_ERR_INVALID, "rt_check_hits: null rays");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dor, dds, dtri, da, db, dt, dhp;
+    int    rc;
+    if ((rc = dor.alloc(12 * n)) || (rc = dds.alloc(12 * n)) || (rc = dtri.alloc(4 * n)) ||
+        (rc = da.alloc(4 * n)) || (rc = db.alloc(4 * n)) || (rc = dt.alloc(4 * n)) ||
+        (rc = dhp.alloc(12 * n)))
+        return rc;
+    HIP_TRY(hipMemcpy(dor.p, origins, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dds.p, dests, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), 0));
+    hipLaunchKernelGGL(k_check_hits, dim3(blocks_for(n, RT_BLOCK)), dim3(RT_BLOCK), stack_bytes(s), 0,
+                       s->d, (long long)n, (const float*)dor.p, (const float*)dds.p, (int*)dtri.p,
+                       (float*)da.p, (float*)db.p, (float*)dt.p, (float*)dhp.p, s->d_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (tri) HIP_TRY(hipMemcpy(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost));
+    if (a) HIP_TRY(hipMemcpy(a, da.p, 4 * n, hipMemcpyDeviceToHost));
+    if (b) HIP_TRY(hipMemcpy(b, db.p, 4 * n, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, dt.p, 4 * n, hipMemcpyDeviceToHost));
+    if (hitpoint) HIP_TRY(hipMemcpy(hitpoint, dhp.p, 12 * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(RtScene* s, const float* lights, int32_t n_lights, const RtParams* params,
+                             int32_t k, float prev_Ni, int64_t n, const float* origins,
+                             const float* dests, float* rgb, float* min_t, int32_t* tri, RtStats* stats)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_trace_rays: null scene");
+    if (k < 0 || k > 5) return fail(RT_ERR_INVALID, "rt_trace_rays: k %d out of range (0..5)", k);
+    if (n < 0 || n > (int64_t)1 << 31) return fail(RT_ERR_INVALID, "rt_trace_rays: n out of range");
+    DParams P;
+    int     rc = make_dparams(params, nullptr, lights, n_lights, &P);
+    if (rc) return rc;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    if (!origins || !dests || !rgb) return fail(RT_ERR_INVALID, "rt_trace_rays: null array");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dor, dds, drgb, dmt, dtri;
+    if ((rc = dor.alloc(12 * n)) || (rc = dds.alloc(12 * n)) || (rc = drgb.alloc(12 * n)) ||
+        (rc = dmt.alloc(4 * n)) || (rc = dtri.alloc(4 * n)))
+        return rc;
+    HIP_TRY(hipMemcpy(dor.p, origins, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dds.p, dests, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), 0));
+    HIP_TRY(hipEventRecord(s->ev0, 0));
+    hipLaunchKernelGGL(k_trace_rays, dim3(blocks_for(n, RT_BLOCK)), dim3(RT_BLOCK), stack_bytes(s), 0,
+                       s->d, P, k, prev_Ni, (long long)n, (const float*)dor.p, (const float*)dds.p,
+                       (float*)drgb.p, (float*)dmt.p, (int*)dtri.p, s->d_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgb, drgb.p, 12 * n, hipMemcpyDeviceToHost));
+    if (min_t) HIP_TRY(hipMemcpy(min_t, dmt.p, 4 * n, hipMemcpyDeviceToHost));
+    if (tri) HIP_TRY(hipMemcpy(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost));
+    if (stats) read_stats(s, stats, 0);
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// frames
+// ---------------------------------------------------------------------------
+static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
+{
+    if (msaa == 1) return RT_OK;
+    if ((size_t)n_slots > s->flags_cap) {
+        if (s->d_flags) (void)hipFree(s->d_flags);
+        s->d_flags = nullptr, s->flags_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_flags, (size_t)n_slots));
+        s->flags_cap = (size_t)n_slots;
+    }
+    const size_t need = (size_t)n_slots * msaa;
+    if (need > s->samples_cap) {
+        if (s->d_samples) (void)hipFree(s->d_samples);
+        s->d_samples = nullptr, s->samples_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_samples, need * sizeof(float4)));
+        s->samples_cap = need;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const float* lights,
+                                      int32_t n_lights, const RtParams* params, float* d_rgb,
+                                      float* d_depth, int32_t* d_tri, void* stream_, RtStats* stats)
+{
+    if (!s || !camera || !d_rgb || !d_depth)
+        return fail(RT_ERR_INVALID, "rt_render_frame: null argument");
+    DParams P;
+    int     rc = make_dparams(params, camera, lights, n_lights, &P);
+    if (rc) return rc;
+    if ((rc = set_partition(params, params->rank, &P))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(s->device));
+    const long long n_slots = (long long)P.n_my_tiles * P.tile_w * P.tile_h;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if ((rc = ensure_workspace(s, n_slots, P.msaa))) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), stream));
+    if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
+    if (n_slots > 0) {
+        const size_t lds = stack_bytes(s);
+        if (P.msaa == 1) {
+            hipLaunchKernelGGL(k_centre<true>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
+                               stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, (unsigned char*)nullptr,
+                               s->d_ctr);
+            HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_centre<false>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
+                               stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, s->d_flags, s->d_ctr);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_samples, dim3(blocks_for(n_slots * P.msaa, RT_BLOCK)), dim3(RT_BLOCK),
+                               lds, stream, s->d, P, n_slots, (const unsigned char*)s->d_flags,
+                               s->d_samples, s->d_ctr);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_slots, 256)), dim3(256), 0, stream, P,
+                               n_slots, (const unsigned char*)s->d_flags,
+                               (const float4*)s->d_samples, d_rgb, d_depth);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev1, stream));
+        read_stats(s, stats, stream);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render_frame(RtScene* s, const float camera[24], const float* lights,
+                               int32_t n_lights, const RtParams* params, float* rgb, float* depth,
+                               int32_t* tri, RtStats* stats)
+{
+    if (!s || !params || !rgb || !depth) return fail(RT_ERR_INVALID, "rt_render_frame: null argument");
+    if (params->width < 2 || params->height < 2 || params->width > 32768 || params->height > 32768)
+        return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", params->width,
+                    params->height);
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)params->width * params->height;
+    DevBuf       drgb, ddepth, dtri;
+    int          rc;
+    if ((rc = drgb.alloc(12 * npx)) || (rc = ddepth.alloc(4 * npx)) || (rc = dtri.alloc(4 * npx)))
+        return rc;
+    HIP_TRY(hipMemset(drgb.p, 0, 12 * npx));
+    HIP_TRY(hipMemset(ddepth.p, 0, 4 * npx));
+    HIP_TRY(hipMemset(dtri.p, 0xff, 4 * npx));
+    RtStats local;
+    rc = rt_render_frame_device(s, camera, lights, n_lights, params, (float*)drgb.p, (float*)ddepth.p,
+                                (int32_t*)dtri.p, nullptr, stats ? stats : &local);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(rgb, drgb.p, 12 * npx, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(depth, ddepth.p, 4 * npx, hipMemcpyDeviceToHost));
+    if (tri) HIP_TRY(hipMemcpy(tri, dtri.p, 4 * npx, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// post-process
+// ---------------------------------------------------------------------------
+#define RANGE_BLOCKS 1024
+
+static int check_device(int device)
+{
+    const int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+static int normalize_depth_impl(int64_t n, float focus, float* d_depth, float* d_part, hipStream_t st)
+{
+    const int nb = (int)std::min<long long>(RANGE_BLOCKS, (n + 255) / 256);
+    hipLaunchKernelGGL(k_depth_range_partial, dim3(nb), dim3(256), 0, st, (const float*)d_depth,
+                       (long long)n, d_part, d_part + RANGE_BLOCKS);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_depth_normalize, dim3(nb), dim3(256), 0, st, d_depth, (long long)n,
+                       (const float*)d_part, (const float*)(d_part + RANGE_BLOCKS), nb, focus);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_normalize_depth_device(int device, int64_t n, float focus, float* d_depth,
+                                         void* stream)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n < 0) return fail(RT_ERR_INVALID, "rt_normalize_depth: negative n");
+    if (n == 0) return RT_OK;
+    if (!d_depth) return fail(RT_ERR_INVALID, "rt_normalize_depth: null depth");
+    float* d_part = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_part, 2 * RANGE_BLOCKS * sizeof(float), (hipStream_t)stream));
+    rc = normalize_depth_impl(n, focus, d_depth, d_part, (hipStream_t)stream);
+    (void)hipFreeAsync(d_part, (hipStream_t)stream);
+    return rc;
+}
+
+extern "C" int rt_normalize_depth(int device, int64_t n, float focus, float* depth)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n < 0) return fail(RT_ERR_INVALID, "rt_normalize_depth: negative n");
+    if (n == 0) return RT_OK;
+    if (!depth) return fail(RT_ERR_INVALID, "rt_normalize_depth: null depth");
+    DevBuf d, part;
+    if ((rc = d.alloc(4 * n)) || (rc = part.alloc(2 * RANGE_BLOCKS * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpy(d.p, depth, 4 * n, hipMemcpyHostToDevice));
+    if ((rc = normalize_depth_impl(n, focus, (float*)d.p, (float*)part.p, 0))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(depth, d.p, 4 * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_dof_blur_device(int device, int32_t W, int32_t H, float depth_power,
+                                  const float* d_rgb, const float* d_depth_n, float* d_out,
+                                  void* stream)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (W < 13 || H < 13 || W > 32768 || H > 32768)
+        return fail(RT_ERR_INVALID, "rt_dof_blur: frame %dx%d must be at least 13x13", W, H);
+    if (!d_rgb || !d_depth_n || !d_out) return fail(RT_ERR_INVALID, "rt_dof_blur: null argument");
+    const long long n = (long long)(W - 12) * (H - 12);
+    hipLaunchKernelGGL(k_dof_blur, dim3(blocks_for(n, DOF_BLOCK)), dim3(DOF_BLOCK), 0,
+                       (hipStream_t)stream, d_rgb, d_depth_n, (int)W, (int)H, depth_power, d_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, const float* rgb,
+                           const float* depth_n, float* out)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (W < 13 || H < 13 || W > 32768 || H > 32768)
+        return fail(RT_ERR_INVALID, "rt_dof_blur: frame %dx%d must be at least 13x13", W, H);
+    if (!rgb || !depth_n || !out) return fail(RT_ERR_INVALID, "rt_dof_blur: null argument");
+    const size_t npx = (size_t)W * H, nout = (size_t)(W - 12) * (H - 12);
+    DevBuf       drgb, dd, dout;
+    if ((rc = drgb.alloc(12 * npx)) || (rc = dd.alloc(4 * npx)) || (rc = dout.alloc(12 * nout)))
+        return rc;
+    HIP_TRY(hipMemcpy(drgb.p, rgb, 12 * npx, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd.p, depth_n, 4 * npx, hipMemcpyHostToDevice));
+    if ((rc = rt_dof_blur_device(device, W, H, depth_power, (const float*)drgb.p, (const float*)dd.p,
+                                 (float*)dout.p, nullptr)))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, 12 * nout, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_quantize(int device, int64_t n, const float* v, uint8_t* out)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n < 0) return fail(RT_ERR_INVALID, "rt_quantize: negative n");
+    if (n == 0) return RT_OK;
+    if (!v || !out) return fail(RT_ERR_INVALID, "rt_quantize: null argument");
+    DevBuf dv, dout;
+    if ((rc = dv.alloc(4 * n)) || (rc = dout.alloc(n))) return rc;
+    HIP_TRY(hipMemcpy(dv.p, v, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(n, 256)), dim3(256), 0, 0, (const float*)dv.p,
+                       (long long)n, (unsigned char*)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tiles
+// ---------------------------------------------------------------------------
+extern "C" int rt_pack_tiles_device(int device, const RtParams* params, const float* d_rgb,
+                                    const float* d_depth, float* d_payload, void* stream)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (!params || !d_rgb || !d_depth || !d_payload)
+        return fail(RT_ERR_INVALID, "rt_pack_tiles: null argument");
+    DParams P;
+    memset(&P, 0, sizeof P);
+    P.W = params->width, P.H = params->height;
+    if ((rc = set_partition(params, params->rank, &P))) return rc;
+    const long long n = (long long)P.n_my_tiles * P.tile_w * P.tile_h;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, P, n,
+                       d_rgb, d_depth, (float4*)d_payload);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_unpack_tiles_device(int device, const RtParams* params, int32_t src_rank,
+                                      const float* d_payload, float* d_rgb, float* d_depth,
+                                      void* stream)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (!params || !d_rgb || !d_depth || !d_payload)
+        return fail(RT_ERR_INVALID, "rt_unpack_tiles: null argument");
+    DParams P;
+    memset(&P, 0, sizeof P);
+    P.W = params->width, P.H = params->height;
+    if ((rc = set_partition(params, src_rank, &P))) return rc;
+    const long long n = (long long)P.n_my_tiles * P.tile_w * P.tile_h;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, P,
+                       n, (const float4*)d_payload, d_rgb, d_depth);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}

@@ -1,0 +1,396 @@
+// rt_device.h - device-side data layout and the per-ray device functions of
+// the gfx950 ray tracer (KD traversal, ray/triangle test, shading).
+//
+// Numerics contract: every operation that decides geometry (which triangle is
+// hit, where, and the rays spawned from there) is evaluated in the reference's
+// own order with separately rounded multiplies and adds, so the results are
+// bit-identical to the reference compiled for x86-64 (no fused multiply-add
+// there).  This file is compiled with -ffp-contract=off and additionally
+// carries the pragma below.  Colour accumulation uses path weights instead of
+// the reference's recursion (it is linear in the child colours), which moves
+// rounding by a few ulp only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define RT_FLT_MAX 3.402823466e+38f
+#define RT_MAX_LIGHTS_DEV 64
+#define RT_MAX_PENDING 6
+
+// One KD node, 16 bytes, nodes in breadth-first order so that the two
+// children of a node are adjacent (right = left + 1) and depth grows with the
+// index.  KDtree.h:9-27 holds six bounds per node; only the split plane
+// (leftChild's end on the node's axis, KDtree.cpp:245-264) is needed here.
+struct DNode {
+    float   split;
+    int32_t left;     // index of the left child, -1 for a leaf
+    int32_t tri_off;  // first triangle slot of this node
+    int32_t cnt_axis; // triangle count | axis << 28
+};
+
+// Triangle slots follow node order (breadth first), ascending inside a node,
+// so a larger slot index = tested later by the reference's walk on the same
+// root-to-leaf path (raytracing.cpp:311-338): ties in t go to the larger slot.
+// Three float4 per slot:
+//   q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
+//   q1 = e2.y e2.z v2.x v2.y
+//   q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
+struct DScene {
+    const DNode*   nodes;
+    const float4*  tris;
+    const float4*  tri_shade; // per original triangle: 3 float4 = nA nB nC (xyz) + w: material, t0|t1.., see pack
+    const int4*    tri_info;  // per original triangle: material, t0, t1, t2
+    const float*   texcoords; // 3 per entry
+    const float4*  mats;      // 4 float4 per material: Kd.xyz Ns | Ks.xyz Ni | illum has_Ni tex _ | pad
+    const int4*    tex_info;  // per texture: byte offset, width, height, 0
+    const uint8_t* texels;
+    int32_t        n_nodes, n_slots, n_triangles, stack_entries;
+};
+
+struct DParams {
+    int32_t W, H, msaa, n_lights;
+    float   backgroundlighting, diffusePower, ShadowFactor, pad0;
+    float   bg[3];
+    float   pad1;
+    int32_t tile_w, tile_h, rank, world;
+    int32_t tiles_x, tiles_y, n_my_tiles, pad2;
+    float   cam[24];
+    float   lights[3 * RT_MAX_LIGHTS_DEV];
+};
+
+struct DCounters {
+    unsigned long long rays_closest, rays_shadow, tri_tests, node_visits, camera_rays;
+};
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+// Vec3D.h:12-18 (vector times float)
+__device__ __forceinline__ f3 operator*(f3 a, float f) { return f3{a.x * f, a.y * f, a.z * f}; }
+// Vec3D.h:192-194
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Vec3D.h:142-151: length by sqrt, then multiply by the reciprocal
+__device__ __forceinline__ float normalize3(f3& a)
+{
+    float len = __fsqrt_rn(dot3(a, a));
+    if (len == 0.0f) return 0.0f;
+    float rez = __fdiv_rn(1.0f, len);
+    a.x *= rez;
+    a.y *= rez;
+    a.z *= rez;
+    return len;
+}
+
+struct HitRec {
+    int   slot; // -1: miss
+    float a, b, t;
+};
+
+// Ray/triangle test, raytracing.cpp:354-386 with Matrix33.h:124-139 spelled
+// out.  det(P0,P1,P2) = P0x*P1y*P2z + P1x*P2y*P0z + P2x*P0y*P1z
+//                     - P0z*P1y*P2x - P1z*P2y*P0x - P2z*P0y*P1x,
+// every triple product as (x*y)*z and the sum left to right.
+__device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, f3 o,
+                                         f3 d, float minT, float& a, float& b, float& t)
+{
+    const float e1x = q0.x, e1y = q0.y, e1z = q0.z, e2x = q0.w, e2y = q1.x, e2z = q1.y;
+    const float cx = o.x - q1.z, cy = o.y - q1.w, cz = o.z - q2.x;
+    const float p1 = q2.y, p4 = q2.z; // e1x*e2y, e1z*e2y
+    const float e2x_dy = e2x * d.y, dx_e1y = d.x * e1y, e2z_dy = e2z * d.y, dz_e1y = d.z * e1y;
+    const float D = p1 * d.z + e2x_dy * e1z + dx_e1y * e2z - p4 * d.x - e2z_dy * e1x - dz_e1y * e2x;
+    if (D == 0.0f) { // Matrix33.h:132-134: solve() returns (0,0,0); t = -0.0f
+        a = 0.0f;
+        b = 0.0f;
+        t = -0.0f;
+    } else {
+        const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
+                         e2z_dy * cx - (d.z * cy) * e2x;
+        const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
+                         (cz * d.y) * e1x - dz_e1y * cx;
+        const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
+                         (cz * e1y) * e2x;
+        a = __fdiv_rn(da, D);
+        b = __fdiv_rn(db, D);
+        t = -__fdiv_rn(dt, D);
+    }
+    return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
+}
+
+#define RT_TRAV_EPS 1e-5f
+
+// Closest-hit (ANY = false) or any-hit (ANY = true) query over the KD tree.
+// Iterative, front to back, with a per-thread stack of (far child, entry t)
+// kept in LDS at stk[entry * stride].  The exit t of a popped subtree is the
+// entry t of the stack entry below it, so it is not stored.  The result equals
+// the reference's leaf walk (raytracing.cpp:281-351): the smallest t over all
+// triangles, ties to the triangle the walk would have tested last.
+template <bool ANY>
+__device__ __forceinline__ bool kd_trace(const DScene& S, f3 o, f3 dst, uint2* stk, int stride,
+                                         HitRec& h, unsigned& n_tests, unsigned& n_nodes)
+{
+    const f3 d = dst - o; // raytracing.cpp:284
+    float    minT = RT_FLT_MAX;
+    h.slot = -1, h.a = 0.0f, h.b = 0.0f;
+    int   node = 0, sp = 0;
+    float tmin = 0.0f, tmax = RT_FLT_MAX;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    if (S.n_nodes == 0) {
+        h.t = minT;
+        return false;
+    }
+    for (;;) {
+        const DNode nd = S.nodes[node];
+        ++n_nodes;
+        const int cnt = nd.cnt_axis & 0x0fffffff;
+        for (int i = 0; i < cnt; ++i) {
+            const int    slot = nd.tri_off + i;
+            const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
+            float        a, b, t;
+            ++n_tests;
+            if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
+                if (ANY) return true;
+                if (t != minT || slot > h.slot) h.slot = slot, h.a = a, h.b = b, minT = t;
+            }
+        }
+        if (nd.left >= 0) {
+            const int   axis = nd.cnt_axis >> 28;
+            const float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+            const float ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
+            const bool  below = (oa < nd.split) || (oa == nd.split && da <= 0.0f);
+            const int   first = nd.left + (below ? 0 : 1), second = nd.left + (below ? 1 : 0);
+            const float tplane = (nd.split - oa) * ia;
+            if (da == 0.0f || tplane <= 0.0f || !(tplane <= tmax * (1.0f + RT_TRAV_EPS))) {
+                node = first;
+            } else if (tplane < tmin * (1.0f - RT_TRAV_EPS)) {
+                node = second;
+            } else {
+                stk[sp * stride] = make_uint2((unsigned)second, __float_as_uint(tplane));
+                ++sp;
+                node = first;
+                tmax = tplane;
+            }
+            continue;
+        }
+        // leaf: next subtree that can still hold a closer hit
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            const uint2 e = stk[sp * stride];
+            const float et = __uint_as_float(e.y);
+            if (!ANY && et > minT * (1.0f + RT_TRAV_EPS)) continue;
+            node = (int)e.x;
+            tmin = et;
+            tmax = sp > 0 ? __uint_as_float(stk[(sp - 1) * stride].y) : RT_FLT_MAX;
+            found = true;
+            break;
+        }
+        if (!found) break;
+    }
+    h.t = minT;
+    return h.slot >= 0;
+}
+
+// Material::getTexture / getTexture2, mesh.cpp:485-553: nearest texel of a
+// planar world-x/y mapping.  The texel index can reach one row past the image;
+// textures carry two zero rows.
+__device__ __forceinline__ f3 sample_texture(const DScene& S, int tex, int4 info, f3 hp)
+{
+    const float* t0 = S.texcoords + 3 * info.y;
+    const float* t1 = S.texcoords + 3 * info.z;
+    const float* t2 = S.texcoords + 3 * info.w;
+    float        width, height;
+    if ((double)fabsf(t0[0] - t2[0]) > 0.0001) width = __fdiv_rn(hp.x, t0[0] - t2[0]);
+    else if ((double)fabsf(t0[0] - t1[0]) > 0.0001) width = __fdiv_rn(hp.x, t0[0] - t1[0]);
+    else width = 0.0f;
+    if ((double)fabsf(t0[1] - t2[1]) > 0.0001) height = __fdiv_rn(hp.y, t0[1] - t2[1]);
+    else if ((double)fabsf(t0[1] - t1[1]) > 0.0001) height = __fdiv_rn(hp.y, t0[1] - t1[1]);
+    else height = 0.0f;
+    float u = width, v = height;
+    if (u > 0.0f) u = u - (float)(int)u;
+    else u = u - (float)(int)u + 1.0f;
+    if (v > 0.0f) v = v - (float)(int)v;
+    else v = v - (float)(int)v + 1.0f;
+    const int4 ti = S.tex_info[tex];
+    int        pos = (int)(u * (float)ti.y + (float)((int)(v * (float)ti.z) * ti.y));
+    const int  last = (ti.z + 2) * ti.y - 1;
+    pos = pos < 0 ? 0 : (pos > last ? last : pos);
+    const uint8_t* px = S.texels + (size_t)ti.x + (size_t)pos * 4;
+    return mk3(__fdiv_rn((float)px[0], 255.0f), __fdiv_rn((float)px[1], 255.0f),
+               __fdiv_rn((float)px[2], 255.0f));
+}
+
+struct PendingRay {
+    f3    o, d;
+    float w;  // path weight of this ray's colour in the camera sample
+    float ni; // prev_Ni handed to performRayTracing
+    int   k;
+};
+
+// One camera sample: performRayTracing(origin, dest, k0, prev_ni, minT) of
+// raytracing.cpp:61-274, with the recursion unrolled into a list of pending
+// rays carrying path weights.
+__device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, f3 origin, f3 dest,
+                                             int k0, float prev_ni, uint2* stk, int stride, f3& rgb, float& minT_out,
+                                             int& tri_out, unsigned& n_closest, unsigned& n_shadow,
+                                             unsigned& n_tests, unsigned& n_nodes)
+{
+    PendingRay pend[RT_MAX_PENDING];
+    int        np = 1;
+    pend[0].o = origin, pend[0].d = dest, pend[0].w = 1.0f, pend[0].ni = prev_ni, pend[0].k = k0;
+    f3   acc = mk3(0.0f, 0.0f, 0.0f);
+    bool first = true;
+    const float shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
+    while (np > 0) {
+        const PendingRay r = pend[--np];
+        HitRec           hit;
+        ++n_closest;
+        const bool got = kd_trace<false>(S, r.o, r.d, stk, stride, hit, n_tests, n_nodes);
+        int orig = -1;
+        if (got) orig = __float_as_int(S.tris[3 * hit.slot + 2].w);
+        if (first) {
+            minT_out = hit.t;
+            tri_out = orig;
+            first = false;
+        }
+        if (!got) { // raytracing.cpp:74
+            acc = acc + mk3(P.bg[0], P.bg[1], P.bg[2]) * r.w;
+            continue;
+        }
+        const f3     dir = r.d - r.o;
+        const f3     hp = r.o + dir * hit.t; // raytracing.cpp:384
+        const float4 s0 = S.tri_shade[3 * orig], s1 = S.tri_shade[3 * orig + 1],
+                     s2 = S.tri_shade[3 * orig + 2];
+        const int4   info = S.tri_info[orig];
+        const float4 m0 = S.mats[4 * info.x], m1 = S.mats[4 * info.x + 1], m2 = S.mats[4 * info.x + 2];
+        const f3     Kd = mk3(m0.x, m0.y, m0.z), Ks = mk3(m1.x, m1.y, m1.z);
+        const float  Ns = m0.w, Ni = m1.w;
+        const int    illum = __float_as_int(m2.x), has_Ni = __float_as_int(m2.y),
+                  tex = __float_as_int(m2.z);
+        // raytracing.cpp:83-85
+        const float u = hit.a, v = hit.b, w = 1.0f - u - v;
+        f3 N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
+        normalize3(N);
+        f3 res;
+        if (tex < 0) res = Kd * P.backgroundlighting; // raytracing.cpp:92-95
+        else res = sample_texture(S, tex, info, hp);
+        float shadowMax = 0.0f; // never reset between lights (raytracing.cpp:104)
+        f3    viewDir = r.o - hp;
+        normalize3(viewDir);
+        for (int li = 0; li < P.n_lights; ++li) { // raytracing.cpp:110-164
+            const f3 lpos = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
+            f3       lightDir = lpos - hp;
+            normalize3(lightDir);
+            float angle = dot3(N, lightDir);
+            if (angle > 0.0f) res = res + (Kd * angle) * P.diffusePower;
+            angle = dot3(lightDir, N);
+            if (angle <= 0.2f) shadowMax = 1.0f;
+            else if (angle < 0.5f) {
+                angle -= 0.2f;
+                shadowMax = 3.33f * (0.3f - angle);
+            }
+            if (angle > 0.0f) {
+                f3 halfway = lightDir + viewDir;
+                normalize3(halfway);
+                angle = dot3(N, halfway);
+                if (angle > 0.0f) res = res + Ks * powf(angle, Ns);
+                HitRec sh;
+                ++n_shadow;
+                if (kd_trace<true>(S, hp + lightDir * 0.001f, lpos, stk, stride, sh, n_tests, n_nodes))
+                    shadowMax = 1.0f;
+            }
+            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow = 0)
+            const float sm = shadowMax * shadowPart;
+            res = res - mk3(sm, sm, sm);
+        }
+        const int newK = r.k + 1;
+        if (newK >= 5) { // raytracing.cpp:166-168
+            acc = acc + res * r.w;
+            continue;
+        }
+        const float n1 = (r.ni != 0.0f) ? r.ni : 1.0f;
+        const float n2 = has_Ni ? Ni : 1.0f;
+        if (illum == 3) { // raytracing.cpp:177-197
+            const f3 refl = dir - N * (2.0f * dot3(N, dir));
+            acc = acc + res * (0.5f * r.w);
+            PendingRay& c = pend[np++];
+            c.o = hp + refl * 0.001f, c.d = hp + refl, c.w = 0.5f * r.w, c.ni = n2, c.k = newK;
+            continue;
+        }
+        if (Ni > 1.0f) { // raytracing.cpp:206-271
+            f3 I = dir;
+            normalize3(I);
+            const float eta = (n1 != n2) ? n2 : __fdiv_rn(1.0f, n2);
+            const float cosI = dot3(I, N);
+            // pow(float, int) is evaluated in double there (raytracing.cpp:221)
+            const float sin2T =
+                (float)(((double)eta * (double)eta) * (1.0 - ((double)cosI * (double)cosI)));
+            float rf = sin2T;
+            rf = rf < 0.0f ? 0.0f : rf;
+            rf = rf > 1.0f ? 1.0f : rf;
+            float wLocal = 0.5f * rf;
+            if (sin2T <= 1.0f) {
+                // sqrt is the double overload in that translation unit (raytracing.cpp:229)
+                const float f = (float)((double)(eta * cosI) - sqrt((double)(1.0f - sin2T)));
+                const f3    tRay = I * eta + N * f;
+                wLocal += 0.1f * (1.0f - rf);
+                const float wT = 0.9f * (1.0f - rf) * r.w;
+                if (wT != 0.0f) {
+                    PendingRay& c = pend[np++];
+                    c.o = hp + tRay * 0.001f, c.d = hp + tRay, c.w = wT, c.ni = n2, c.k = newK;
+                }
+            }
+            const float wR = 0.5f * rf * r.w;
+            if (wR != 0.0f) {
+                const f3    refRay = I - N * (2.0f * dot3(I, N));
+                PendingRay& c = pend[np++];
+                c.o = hp + refRay * 0.001f, c.d = hp + refRay, c.w = wR, c.ni = n2, c.k = newK;
+            }
+            acc = acc + res * (wLocal * r.w);
+            continue;
+        }
+        acc = acc + res * r.w;
+    }
+    rgb = acc;
+}
+
+// RayTracer::raytrace, main.cpp:514-526: bilinear blend of the corner rays;
+// the weights are formed in double and converted to float before they touch
+// the vectors (Vec3D.h:12-18).
+__device__ __forceinline__ void pixel_ray(const DParams& P, double x, double y, f3& o, f3& d)
+{
+    const double xscale = 1.0 - x / (double)(P.W - 1);
+    const double yscale = 1.0 - y / (double)(P.H - 1);
+    const float  xs = (float)xscale, xs1 = (float)(1 - xscale), ys = (float)yscale,
+                ys1 = (float)(1 - yscale);
+    const float* c = P.cam;
+    const f3 o00 = mk3(c[0], c[1], c[2]), d00 = mk3(c[3], c[4], c[5]), o01 = mk3(c[6], c[7], c[8]),
+             d01 = mk3(c[9], c[10], c[11]), o10 = mk3(c[12], c[13], c[14]),
+             d10 = mk3(c[15], c[16], c[17]), o11 = mk3(c[18], c[19], c[20]),
+             d11 = mk3(c[21], c[22], c[23]);
+    o = (o00 * xs + o10 * xs1) * ys + (o01 * xs + o11 * xs1) * ys1;
+    d = (d00 * xs + d10 * xs1) * ys + (d01 * xs + d11 * xs1) * ys1;
+}
+
+// Pixel slot -> pixel.  Slots enumerate this rank's tiles in order; inside a
+// tile pixels go by 8x8 blocks so that the 64 lanes of a wave cover a compact
+// screen area.
+__device__ __forceinline__ bool slot_to_pixel(const DParams& P, long long slot, int& x, int& y)
+{
+    const int       tile_px = P.tile_w * P.tile_h;
+    const long long lt = slot / tile_px;
+    const int       within = (int)(slot - lt * tile_px);
+    if (lt >= P.n_my_tiles) return false;
+    const long long gt = lt * P.world + P.rank;
+    const int       tx = (int)(gt % P.tiles_x), ty = (int)(gt / P.tiles_x);
+    const int       blk = within >> 6, in = within & 63;
+    const int       bpr = P.tile_w >> 3; // 8x8 blocks per tile row
+    x = tx * P.tile_w + (blk % bpr) * 8 + (in & 7);
+    y = ty * P.tile_h + (blk / bpr) * 8 + (in >> 3);
+    return x < P.W && y < P.H;
+}
