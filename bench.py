@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames of final.obj at 3840x2160, MSAA 4, depth 5, with the
+depth-of-field pass, on N GPUs of one node (BASELINE.json configs[4]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame: every rank traces its screen tiles (32x32, dealt
+round-robin), the tile payloads are gathered on rank 0 (RCCL), rank 0 runs the
+depth normalisation (twice, as the reference does) and the blur.  Scene,
+camera and lights are resident on the GPUs before the timed region; the frame
+stays in HBM.  Rank 0 prints one JSON line.
+
+value = rays traced by all ranks per second (closest-hit + shadow queries the
+GPUs executed).  roofline.achieved = algorithmic FLOP of the dominant kernel
+(k_samples: the four MSAA samples of every pixel whose centre ray hit) divided
+by its mean duration from HIP events recorded inside the timed loop; the FLOP
+count is F = 45 T + 40 S + 30 H + 60 Hl + 25 C with the counters of the
+reference's algorithm (tests/golden/frame_counters.json, produced by
+tools/make_counters.py on the CPU oracle), frame minus centre rays.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENE, W, H, MSAA = "final", 3840, 2160, 4
+TILE = 32
+FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak (= f32 MFMA peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(corners, lights):
+    """The oracle (CPU restatement of the reference) on a bounded sample of the
+    same frame: 6 bands of rows spread over the image, all host threads we may
+    use.  Checker code used as a reported baseline, never as the product."""
+    from oracle import oracle as O
+    threads = max(1, min(16, os.cpu_count() or 1))
+    s = O.Scene.load(os.path.join(ROOT, "scenes", SCENE + ".obj"))
+    s.set_lights(lights)
+    s.settings.MSAA = MSAA
+    bands = 6
+
+    def sample(rows):
+        c = O.Counters()
+        out = None
+        t0 = time.perf_counter()
+        for b in range(bands):
+            y0 = min(int((b + 0.5) * H / bands), H - rows)
+            out = s.render(corners, W, H, y0=y0, y1=y0 + rows, threads=threads, counters=c, out=out)
+        return c, time.perf_counter() - t0
+
+    rows = 2
+    c, dt = sample(rows)                       # calibration pass
+    target = 15.0                              # seconds of CPU wall time for the timed sample
+    rows = int(max(2, min(H // bands, rows * target / max(dt, 1e-3))))
+    c, dt = sample(rows)
+    rays = c.rays_closest + c.rays_shadow
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{bands * rows} of {H} rows ({bands} bands) of {SCENE}.obj {W}x{H} MSAA{MSAA}, "
+                      f"no DoF, {dt:.1f} s",
+            "ms_per_frame_extrapolated": round(dt * H / (bands * rows) * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("raytracing-project_amd")
+    capi, host = pkg.capi, pkg.host
+    import ctypes as C
+
+    hs = host.HostScene(os.path.join(ROOT, "scenes", SCENE + ".obj"))
+    gs = hs.to_gpu(local)
+    m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", SCENE + ".sav"))
+    corners = host.camera_corners(m, W, H)
+    p = capi.default_params(W, H, MSAA)
+    p.tile_w = p.tile_h = TILE
+    p.rank, p.world = rank, world
+
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    depth = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    blurred = torch.zeros((H - 12, W - 12, 3), dtype=torch.float32, device=dev)
+    n_slots = capi.lib().rt_tile_pixels(C.byref(p), rank)
+    payload = torch.zeros((n_slots, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    L = capi.lib()
+
+    def unpack(src, buf):
+        capi.check(L.rt_unpack_tiles_device(local, C.byref(p), src, C.c_void_p(buf.data_ptr()),
+                                            C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                            C.c_void_p(stream)))
+
+    def frame(stats=False):
+        st = gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, stream, stats)
+        if world > 1:
+            capi.check(L.rt_pack_tiles_device(local, C.byref(p), C.c_void_p(rgb.data_ptr()),
+                                              C.c_void_p(depth.data_ptr()),
+                                              C.c_void_p(payload.data_ptr()), C.c_void_p(stream)))
+            pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack)
+        if rank == 0:
+            # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
+            for _ in range(2):
+                capi.check(L.rt_normalize_depth_device(local, W * H, p.focusDepth,
+                                                       C.c_void_p(depth.data_ptr()), C.c_void_p(stream)))
+            capi.check(L.rt_dof_blur_device(local, W, H, p.depthPower, C.c_void_p(rgb.data_ptr()),
+                                            C.c_void_p(depth.data_ptr()),
+                                            C.c_void_p(blurred.data_ptr()), C.c_void_p(stream)))
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one counted frame: rays this rank traces per frame (deterministic)
+    st = frame(stats=True)
+    my_rays = st.rays_closest + st.rays_shadow
+    my = torch.tensor([float(my_rays), float(st.tri_tests), float(st.node_visits)],
+                      dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(my)
+    rays_per_frame, tests_per_frame, nodes_per_frame = (float(x) for x in my.tolist())
+
+    for _ in range(args.warmup):
+        frame()
+    gs.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = gs.collect_timing()
+    gs.set_timing(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (all bounces), final.obj 3840x2160 MSAA4 + DoF; ms/frame in ms_per_step",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "scenes/final.obj + scenes/cameras/final.sav (the reference's own scene; no "
+                    "published camera exists, this one is fixed in the repo)",
+            "config": {"workload": f"{SCENE}.obj {W}x{H} MSAA{MSAA} + DoF, {len(lights)} lights, "
+                                   "reflection/refraction depth 5",
+                       "partition": f"{TILE}x{TILE} tiles round-robin over {world} GPU(s), "
+                                    "RCCL gather to rank 0" if world > 1 else f"{TILE}x{TILE} tiles, 1 GPU",
+                       "rays_per_frame": int(rays_per_frame),
+                       "tri_tests_per_ray": round(tests_per_frame / rays_per_frame, 2),
+                       "nodes_per_ray": round(nodes_per_frame / rays_per_frame, 2)},
+        }
+        # roofline of the dominant kernel (rank 0's launches)
+        fc_path = os.path.join(ROOT, "tests", "golden", "frame_counters.json")
+        key = f"{SCENE}_{W}x{H}_msaa{MSAA}"
+        roof = None
+        if os.path.exists(fc_path) and kt.samples_launches > 0:
+            fc = json.load(open(fc_path)).get(key)
+            if fc:
+                f_samples = (fc["flops_frame"] - fc["flops_centre"]) / world  # this rank's share
+                dur = kt.samples_ms / kt.samples_launches * 1e-3
+                ach = f_samples / dur / 1e12
+                traffic = None
+                tp = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tp):
+                    traffic = json.load(open(tp)).get("k_samples_hbm_bytes_per_launch")
+                roof = {"bound": "valu", "kernel": "k_samples", "achieved": round(ach, 3),
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                        "traffic": traffic,
+                        "kernel_ms": round(dur * 1e3, 3),
+                        "algorithmic_gflop_per_launch": round(f_samples / 1e9, 2),
+                        "note": "no MFMA on this path: FP32 vector peak (equal to the f32 MFMA peak)",
+                        "frame": {"algorithmic_gflop": round(fc["flops_frame"] / 1e9, 2),
+                                  "achieved_tflops": round(fc["flops_frame"] / (ms * 1e-3) / 1e12, 3),
+                                  "frac": round(fc["flops_frame"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                  "reference_rays": fc["frame"]["rays_closest"] + fc["frame"]["rays_shadow"]},
+                        "hbm": {"algorithmic_bytes_per_frame": W * H * 16 + W * H * 16 + (W - 12) * (H - 12) * 12,
+                                "achieved_gbs": round((W * H * 32 + (W - 12) * (H - 12) * 12) / (ms * 1e-3) / 1e9, 2),
+                                "peak_gbs": HBM_PEAK_GBS}}
+        out["roofline"] = roof
+        out["kernel_ms"] = {"k_centre": round(kt.centre_ms / max(kt.centre_launches, 1), 3),
+                            "k_samples": round(kt.samples_ms / max(kt.samples_launches, 1), 3),
+                            "k_resolve": round(kt.resolve_ms / max(kt.resolve_launches, 1), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(corners, lights)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

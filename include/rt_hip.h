@@ -119,6 +119,15 @@ typedef struct RtSceneInfo {
     uint64_t device_bytes;
 } RtSceneInfo;
 
+/* Per-kernel device time of the render calls since timing was switched on or
+ * last collected, from HIP events recorded on the render stream around each
+ * launch (no host synchronisation inside the render call). */
+typedef struct RtKernelTimes {
+    double  centre_ms, samples_ms, resolve_ms;
+    int32_t centre_launches, samples_launches, resolve_launches;
+    int32_t reserved;
+} RtKernelTimes;
+
 /* RtParams with the reference's constants. */
 void rt_default_params(RtParams *p, int32_t width, int32_t height);
 
@@ -132,6 +141,13 @@ const char *rt_last_error(void);
 int  rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
 void rt_scene_destroy(RtScene *scene);
 int  rt_scene_info(const RtScene *scene, RtSceneInfo *info);
+/* Bench instrumentation, no counterpart in the reference (its only timer is the
+ * clock() pair of main.cpp:327,368).  rt_scene_set_timing switches event
+ * recording on or off; rt_scene_collect_timing waits for the device, sums the
+ * recorded intervals per kernel and resets them.  At most 4096 launches are
+ * kept between two collections; later ones are not timed. */
+int  rt_scene_set_timing(RtScene *scene, int enable);
+int  rt_scene_collect_timing(RtScene *scene, RtKernelTimes *out);
 
 /* checkHit(origin, dest, minT) (raytracing.h:77, raytracing.cpp:281-351) for n
  * rays.  tri is the index into Mesh::triangles of the closest hit, -1 for a

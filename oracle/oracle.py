@@ -97,6 +97,7 @@ def lib():
                                     C.c_int, C.c_int, fp]
     L.or_pixel_ray.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, fp, fp]
     L.or_render_rows.argtypes = [P, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, ip, C.c_int, cp]
+    L.or_render_rows2.argtypes = [P, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, ip, C.c_int, cp, cp]
     L.or_normalize_depth.argtypes = [fp, C.c_int, C.c_float]
     L.or_gaussian_map.argtypes = [C.c_float, C.c_float, fp]
     L.or_blur.argtypes = [fp, fp, C.c_int, C.c_int, C.c_float, fp, C.c_int]
@@ -257,14 +258,19 @@ class Scene:
         self.L.or_brute_hits(self.h, len(o), o, d, tri, t)
         return tri, t
 
-    def render(self, corners, W, H, y0=0, y1=None, threads=1, counters=None):
+    def render(self, corners, W, H, y0=0, y1=None, threads=1, counters=None, centre=None,
+               out=None):
+        """Rows [y0, y1) of a frame.  `centre` receives the work of the pixel-centre
+        rays alone.  `out` = (rgb, depth, tri) to render several bands into one frame."""
         y1 = H if y1 is None else y1
         corners = _f32(corners).reshape(24)
-        rgb = np.zeros((H, W, 3), np.float32)
-        depth = np.zeros((H, W), np.float32)
-        tri = np.full((H, W), -1, np.int32)
-        self.L.or_render_rows(self.h, corners, W, H, y0, y1, rgb, depth, tri, threads,
-                              C.byref(counters) if counters is not None else None)
+        if out is None:
+            out = (np.zeros((H, W, 3), np.float32), np.zeros((H, W), np.float32),
+                   np.full((H, W), -1, np.int32))
+        rgb, depth, tri = out
+        self.L.or_render_rows2(self.h, corners, W, H, y0, y1, rgb, depth, tri, threads,
+                               C.byref(counters) if counters is not None else None,
+                               C.byref(centre) if centre is not None else None)
         return rgb, depth, tri
 
 
@@ -314,7 +320,8 @@ def read_camera_sav(path):
     """camera.sav as written by the reference (main.cpp:270-280): 16 floats of the
     column-major modelview, the light count, then one light per line."""
     tok = open(path, "rb").read().split()
-    m = np.array([float(x) for x in tok[:16]], np.float64)
+    # fscanf("%f") into a float, then widened (main.cpp:285-288)
+    m = np.array([float(x) for x in tok[:16]], np.float32).astype(np.float64)
     n = int(tok[16])
     lights = np.array([float(x) for x in tok[17:17 + 3 * n]], np.float32).reshape(n, 3)
     return m, lights

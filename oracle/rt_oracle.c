@@ -1286,6 +1286,8 @@ static v3 raytrace(const or_scene *s, const float corners[24], int W, int H, dou
     return perform(s, v3ld(o), v3ld(d), 0, 1.0f, depth, tri, c);
 }
 
+static void counters_add(or_counters *a, const or_counters *b);
+
 /* main.cpp:383-388 */
 static void depth_increase(float *depth, float holder, int *hitNumber)
 {
@@ -1306,12 +1308,16 @@ static const double MSAA16[16][2] = {
 
 /* main.cpp:435-511 */
 static v3 raytrace_msaa(const or_scene *s, const float corners[24], int W, int H, int x, int y,
-                        float *depth, int *primaryTri, or_counters *c)
+                        float *depth, int *primaryTri, or_counters *c, or_counters *centre)
 {
     int   hitNumber = 0;
     float holder;
     *depth = 0;
-    v3 rgb = raytrace(s, corners, W, H, x, y, &holder, primaryTri, c);
+    or_counters cc;
+    memset(&cc, 0, sizeof cc);
+    v3 rgb = raytrace(s, corners, W, H, x, y, &holder, primaryTri, &cc);
+    if (c) counters_add(c, &cc);
+    if (centre) counters_add(centre, &cc);
     depth_increase(depth, holder, &hitNumber);
     if (hitNumber == 0) *depth = FLT_MAX;
     if (hitNumber > 0 && (s->set.MSAA == 4 || s->set.MSAA == 16)) {
@@ -1345,19 +1351,28 @@ static inline float clamp01(float v) /* imageWriter.h:26-44 */
 typedef struct {
     const or_scene *s;
     const float    *corners;
-    int             W, H, y0;
+    int             W, H, y0, chunks;
     float          *rgb, *depth;
     int32_t        *tri;
+    or_counters    *centre;
+    pthread_mutex_t mu;
 } rows_arg;
 
+#define ROW_CHUNK 64
+
+/* one work item = ROW_CHUNK pixels of one row */
 static void render_row(job *j, int i, or_counters *c)
 {
     rows_arg *A = (rows_arg *)j->arg;
-    int       y = A->y0 + i;
-    for (int x = 0; x < A->W; ++x) {
+    int       y = A->y0 + i / A->chunks;
+    int       x0 = (i % A->chunks) * ROW_CHUNK, x1 = x0 + ROW_CHUNK < A->W ? x0 + ROW_CHUNK : A->W;
+    or_counters cen;
+    memset(&cen, 0, sizeof cen);
+    for (int x = x0; x < x1; ++x) {
         float depth;
         int   tri = -1;
-        v3 rgb = raytrace_msaa(A->s, A->corners, A->W, A->H, x, y, &depth, &tri, c);
+        v3 rgb = raytrace_msaa(A->s, A->corners, A->W, A->H, x, y, &depth, &tri, c,
+                               A->centre ? &cen : NULL);
         size_t p = (size_t)y * A->W + x;
         A->rgb[3 * p] = clamp01(rgb.p[0]);
         A->rgb[3 * p + 1] = clamp01(rgb.p[1]);
@@ -1365,13 +1380,26 @@ static void render_row(job *j, int i, or_counters *c)
         A->depth[p] = depth;
         if (A->tri) A->tri[p] = tri;
     }
+    if (A->centre) {
+        pthread_mutex_lock(&A->mu);
+        counters_add(A->centre, &cen);
+        pthread_mutex_unlock(&A->mu);
+    }
+}
+
+void or_render_rows2(const or_scene *s, const float corners[24], int W, int H, int y0, int y1,
+                     float *rgb, float *depth, int32_t *primary_tri, int threads, or_counters *c,
+                     or_counters *centre)
+{
+    rows_arg A = {s, corners, W, H, y0, (W + ROW_CHUNK - 1) / ROW_CHUNK, rgb, depth, primary_tri,
+                  centre, PTHREAD_MUTEX_INITIALIZER};
+    run_job(render_row, (y1 - y0) * A.chunks, 1, &A, threads, c);
 }
 
 void or_render_rows(const or_scene *s, const float corners[24], int W, int H, int y0, int y1,
                     float *rgb, float *depth, int32_t *primary_tri, int threads, or_counters *c)
 {
-    rows_arg A = {s, corners, W, H, y0, rgb, depth, primary_tri};
-    run_job(render_row, y1 - y0, 1, &A, threads, c);
+    or_render_rows2(s, corners, W, H, y0, y1, rgb, depth, primary_tri, threads, c, NULL);
 }
 
 /* ------------------------------------------------------------------ */

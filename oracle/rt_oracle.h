@@ -127,6 +127,12 @@ void or_render_rows(const or_scene *s, const float corners[24], int W, int H, in
                     float *rgb, float *depth, int32_t *primary_tri, int threads,
                     or_counters *c);
 
+/* same; `centre` (may be NULL) additionally receives the work of the pixel-centre
+ * rays alone (the first raytrace() call of main.cpp:440) */
+void or_render_rows2(const or_scene *s, const float corners[24], int W, int H, int y0, int y1,
+                     float *rgb, float *depth, int32_t *primary_tri, int threads, or_counters *c,
+                     or_counters *centre);
+
 /* ---- image: imageWriter.h ---- */
 void or_normalize_depth(float *depth, int n, float focusDepth);
 void or_gaussian_map(float intensity, float depthPower, float map[169]);

@@ -4,4 +4,4 @@ The product is csrc/librt_hip.so (HIP kernels behind the C ABI of include/rt_hip
 csrc/librt_host.so (C++ host side mirroring the reference's raytracing.h surface).
 The Python modules here only bind those libraries for tests and bench.py.
 """
-from . import capi  # noqa: F401
+from . import capi, distributed, host, tiles  # noqa: F401

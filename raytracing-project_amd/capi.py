@@ -64,6 +64,12 @@ class RtStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class RtKernelTimes(C.Structure):
+    _fields_ = [("centre_ms", C.c_double), ("samples_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("centre_launches", C.c_int32), ("samples_launches", C.c_int32),
+                ("resolve_launches", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RtSceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_triangles", C.c_int32), ("tree_depth", C.c_int32),
                 ("n_slots", C.c_int32), ("device_bytes", C.c_uint64)]
@@ -71,7 +77,7 @@ class RtSceneInfo(C.Structure):
 
 EXPORTS = [
     "rt_default_params", "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
-    "rt_scene_info", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device",
+    "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device",
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_dof_blur", "rt_dof_blur_device",
     "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
 ]
@@ -87,6 +93,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch ships its own HIP runtime under the same soname as /opt/rocm's.  Two copies
+    # in one process do not both see the GPU, so when torch is going to be used in this
+    # process (bench.py, tests that allocate device memory with it) it has to be loaded
+    # first; librt_hip.so then binds to the runtime that is already there.
+    if os.environ.get("RT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.rt_default_params.argtypes = [C.POINTER(RtParams), I32, I32]
@@ -97,6 +112,8 @@ def lib():
     L.rt_scene_destroy.argtypes = [P]
     L.rt_scene_destroy.restype = None
     L.rt_scene_info.argtypes = [P, C.POINTER(RtSceneInfo)]
+    L.rt_scene_set_timing.argtypes = [P, C.c_int]
+    L.rt_scene_collect_timing.argtypes = [P, C.POINTER(RtKernelTimes)]
     L.rt_check_hits.argtypes = [P, I64, P, P, P, P, P, P, P]
     L.rt_trace_rays.argtypes = [P, P, I32, C.POINTER(RtParams), I32, F, I64, P, P, P, P, P,
                                 C.POINTER(RtStats)]
@@ -203,6 +220,14 @@ class Scene:
         check(lib().rt_scene_info(self.h, C.byref(i)))
         return {n: getattr(i, n) for n, _ in i._fields_}
 
+    def set_timing(self, enable):
+        check(lib().rt_scene_set_timing(self.h, 1 if enable else 0))
+
+    def collect_timing(self):
+        t = RtKernelTimes()
+        check(lib().rt_scene_collect_timing(self.h, C.byref(t)))
+        return t
+
     def check_hits(self, origins, dests):
         o, d = _f32(origins, (-1, 3)), _f32(dests, (-1, 3))
         n = len(o)
@@ -260,7 +285,7 @@ def dof_blur(rgb, depth_n, depth_power=2.5, device=0):
     rgb = _f32(rgb)
     H, W = rgb.shape[:2]
     dn = _f32(depth_n, (H, W))
-    out = np.zeros((H - 12, W - 12, 3), np.float32)
+    out = np.zeros((max(H - 12, 0), max(W - 12, 0), 3), np.float32)
     check(lib().rt_dof_blur(device, W, H, depth_power, _ptr(rgb), _ptr(dn), _ptr(out)))
     return out
 

@@ -1,0 +1,130 @@
+// image_io.cpp - the four result files of the 'r' path (main.cpp:371-377),
+// byte-compatible with the reference's writers in imageWriter.h:
+//   * 8-bit value = (unsigned char)(v * 255.0f), truncating (imageWriter.h:270);
+//     NaN and values outside the int range become 0, which is what the x86
+//     float->int conversion followed by the narrowing gives;
+//   * BMP: 14 + 40 byte headers, 24 bpp, height stored negative (top-down),
+//     BGR byte order; the size field holds 3*w*h for result.bmp/depth.bmp and
+//     w*h for blurred.bmp, not the file size (imageWriter.h:298-301, 426-430);
+//     rows are laid out with the 4-byte-aligned stride but only 3*w*h bytes are
+//     written (imageWriter.h:316-331), so widths that are not a multiple of 4
+//     come out skewed exactly as the reference's do;
+//   * depth.bmp: grey = 1 - normalised depth, and the reference's inner loop
+//     runs over 3*w "pixels" per row (imageWriter.h:379-389), overwriting the
+//     following rows' start; reproduced by writing in the same order.
+#include <cstdio>
+#include <cstring>
+
+#include "rt_host.hpp"
+
+namespace rtamd {
+
+namespace {
+
+inline unsigned char quantize(float v)
+{
+    const float x = v * 255.0f;
+    if (!(x == x) || x >= 2147483648.0f || x < -2147483648.0f) return 0;
+    return (unsigned char)(int)x;
+}
+
+void putHeaders(FILE* f, unsigned sizeField, int w, int h)
+{
+    unsigned char fh[14] = {'B', 'M', 0, 0, 0, 0, 0, 0, 0, 0, 54, 0, 0, 0};
+    unsigned char ih[40] = {40, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 24, 0};
+    const unsigned uw = (unsigned)w, uh = (unsigned)(-h);
+    for (int i = 0; i < 4; ++i) {
+        fh[2 + i] = (unsigned char)(sizeField >> (8 * i));
+        ih[4 + i] = (unsigned char)(uw >> (8 * i));
+        ih[8 + i] = (unsigned char)(uh >> (8 * i));
+    }
+    fwrite(fh, 1, sizeof fh, f);
+    fwrite(ih, 1, sizeof ih, f);
+}
+
+inline int stride(int w) { return ((24 * w + 31) / 32) * 4; }
+
+bool writeColour(const char* filename, const float* img, int w, int h, unsigned sizeField, int padShift)
+{
+    FILE* f = fopen(filename, "wb");
+    if (!f) {
+        printf("dump file problem... file\n");
+        return false;
+    }
+    putHeaders(f, sizeField, w, h);
+    const int                  rs = stride(w);
+    std::vector<unsigned char> bytes((size_t)rs * h + 8, 0);
+    for (int y = 0; y < h; ++y) {
+        unsigned char* row = bytes.data() + (size_t)y * rs;
+        const float*   src = img + (size_t)y * w * 3;
+        for (int x = 0; x < w; ++x) {
+            row[3 * x] = quantize(src[3 * x + 2]);
+            row[3 * x + 1] = quantize(src[3 * x + 1]);
+            row[3 * x + 2] = quantize(src[3 * x]);
+        }
+        for (int i = 3 * w; i < rs; ++i) row[i - padShift] = 1; // imageWriter.h:326-328 / 456-458
+    }
+    const bool ok = fwrite(bytes.data(), (size_t)w * h * 3, 1, f) == 1;
+    if (!ok) printf("Dump file problem... fwrite\n");
+    fclose(f);
+    return ok;
+}
+
+} // namespace
+
+bool Image::writeImagePPM(const char* filename) const
+{
+    FILE* f = fopen(filename, "wb");
+    if (!f) {
+        printf("dump file problem... file\n");
+        return false;
+    }
+    fprintf(f, "P6\n%i %i\n255\n", width, height);
+    std::vector<unsigned char> bytes(rgb.size());
+    for (size_t i = 0; i < rgb.size(); ++i) bytes[i] = quantize(rgb[i]);
+    const bool ok = fwrite(bytes.data(), (size_t)width * height * 3, 1, f) == 1;
+    fclose(f);
+    return ok;
+}
+
+bool Image::writeImageBMP(const char* filename) const
+{
+    return writeColour(filename, rgb.data(), width, height, (unsigned)(3 * width * height), 0);
+}
+
+bool Image::writeBlurredBMP(const char* filename) const
+{
+    const int bw = width - 12, bh = height - 12;
+    if (bw <= 0 || bh <= 0 || blurred.size() != (size_t)bw * bh * 3) return false;
+    return writeColour(filename, blurred.data(), bw, bh, (unsigned)(bw * bh), 3);
+}
+
+bool Image::writeDepthBMP(const char* filename) const
+{
+    FILE* f = fopen(filename, "wb");
+    if (!f) {
+        printf("dump file problem... file\n");
+        return false;
+    }
+    putHeaders(f, (unsigned)(3 * width * height), width, height);
+    const int                  rs = stride(width);
+    const size_t               npx = (size_t)width * height;
+    std::vector<unsigned char> bytes((size_t)rs * height + (size_t)9 * width + 16, 0);
+    for (int y = 0; y < height; ++y) {
+        int i = 0;
+        for (; i < width * 3; ++i) {
+            const size_t p = (size_t)y * width + i;
+            if (p < npx) {
+                const unsigned char v = quantize(1 - depth[p]);
+                unsigned char*      d = bytes.data() + (size_t)y * rs + (size_t)i * 3;
+                d[0] = d[1] = d[2] = v;
+            }
+        }
+        for (; i < rs; ++i) bytes[(size_t)y * rs + i] = 1;
+    }
+    const bool ok = fwrite(bytes.data(), npx * 3, 1, f) == 1;
+    fclose(f);
+    return ok;
+}
+
+} // namespace rtamd

@@ -1,0 +1,118 @@
+// rt_host.hpp - C++ host side of the gfx950 ray tracer.
+//
+// It keeps the surface the reference's host code programs against
+// (raytracing.h:12-33 in the reference: the globals MyMesh, MyLightPositions,
+// treeRoot, focusDepth and the functions init(), performRayTracing(),
+// checkHit(), plus RayTracer::doDaRayTracingShizz() of main.cpp:322) and
+// forwards the per-pixel work to librt_hip.so.  Scene loading, the KD build,
+// the camera set-up and the image files stay on the host, as in the reference.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_hip.h"
+
+namespace rtamd {
+
+struct Vec3Df {
+    float p[3];
+    Vec3Df() : p{0, 0, 0} {}
+    Vec3Df(float x, float y, float z) : p{x, y, z} {}
+    float&       operator[](int i) { return p[i]; }
+    const float& operator[](int i) const { return p[i]; }
+};
+
+struct Texture {
+    std::string          path;
+    int                  width = 0, height = 0;
+    std::vector<uint8_t> rgba; // width*height*4, top row first
+};
+
+// Mesh of mesh.h:258-291, stored as flat arrays ready for RtSceneDesc.
+struct Mesh {
+    std::vector<float>       positions; // 3 per vertex
+    std::vector<float>       normals;   // 3 per vertex, filled by computeVertexNormals
+    std::vector<float>       texcoords; // 3 per entry
+    std::vector<int32_t>     tri_vertex, tri_texcoord, tri_material;
+    std::vector<RtMaterial>  materials;
+    std::vector<std::string> material_names;
+    std::vector<Texture>     textures;
+
+    size_t vertexCount() const { return positions.size() / 3; }
+    size_t triangleCount() const { return tri_material.size(); }
+    // mesh.cpp:96 (the flag is accepted and ignored there too: mesh.cpp:307)
+    bool loadMesh(const char* filename, bool randomizeTriangulation = true, bool loadTextures = true);
+    // mesh.cpp:32
+    void computeVertexNormals();
+};
+
+// The tree of KDtree.h:9-27 as index-linked nodes.
+struct KdTree {
+    std::vector<RtKdNode> nodes;
+    std::vector<int32_t>  node_tris;
+    int                   depth = 0;
+};
+// KDtree.cpp:15
+void buildKDtree(const Mesh& mesh, KdTree& tree);
+
+// camera.sav of main.cpp:270-307: 16 floats of the column-major modelview,
+// the number of lights, one light per line.
+bool readCameraSav(const char* path, double modelview[16], std::vector<Vec3Df>& lights);
+bool writeCameraSav(const char* path, const double modelview[16], const std::vector<Vec3Df>& lights);
+// The eight corner points of main.cpp:52-55 for gluPerspective(50, w/h, 0.01, 10)
+// (main.cpp:209), viewport (0,0,w,h) and the given modelview.
+void cameraCorners(const double modelview[16], int width, int height, float corners[24]);
+
+// Image of imageWriter.h:81-251 (float planes + the file writers).
+struct Image {
+    int                width = 0, height = 0;
+    std::vector<float> rgb, depth, blurred;
+    Image() {}
+    Image(int w, int h) : width(w), height(h), rgb((size_t)3 * w * h), depth((size_t)w * h) {}
+    bool writeImagePPM(const char* filename) const;
+    bool writeImageBMP(const char* filename) const;
+    bool writeDepthBMP(const char* filename) const;   // expects normalised depth
+    bool writeBlurredBMP(const char* filename) const; // expects `blurred` filled
+};
+
+struct HitTriangle { // raytracing.h:48-54
+    bool    bHit = false;
+    float   a = 0, b = 0;
+    Vec3Df  hitPoint;
+    int32_t triangle = -1; // index into Mesh triangles
+};
+
+// ---- the raytracing.h surface ----
+extern Mesh                MyMesh;
+extern std::vector<Vec3Df> MyLightPositions;
+extern KdTree              MyTree;
+extern float               focusDepth;
+extern RtParams            MySettings; // settings.h + config.h values
+
+// raytracing.h:24.  The reference compiles OBJ_PATH in; here it is an argument.
+// Returns false (and leaves lastError()) when the scene cannot be set up.
+bool init(const char* obj_path, int device = 0, bool loadTextures = true);
+void shutdown();
+const std::string& lastError();
+RtScene*           gpuScene();
+// raytracing.h:33
+Vec3Df performRayTracing(const Vec3Df& origin, const Vec3Df& dest, int k, float prev_Ni, float& minT);
+// raytracing.h:76-77
+HitTriangle checkHit(const Vec3Df& origin, const Vec3Df& dest);
+HitTriangle checkHit(const Vec3Df& origin, const Vec3Df& dest, float& minT);
+
+// RayTracer of main.cpp:41-80: corner rays from the camera, one GPU frame,
+// then the four result files.
+class RayTracer {
+public:
+    RayTracer(const double modelview[16], int width, int height);
+    // main.cpp:322: renders and writes result.ppm, result.bmp, depth.bmp and
+    // blurred.bmp into out_dir; returns the seconds the frame took, < 0 on error.
+    double doDaRayTracingShizz(const char* out_dir = ".");
+    Image   result;
+    RtStats stats{};
+    float   corners[24];
+};
+
+} // namespace rtamd

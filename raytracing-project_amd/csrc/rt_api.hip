@@ -395,7 +395,40 @@ struct RtScene {
     float4*        d_samples = nullptr;
     size_t         samples_cap = 0;
     hipEvent_t     ev0 = nullptr, ev1 = nullptr;
+    // optional per-kernel timing (rt_scene_set_timing)
+    bool                                 timing = false;
+    std::vector<hipEvent_t>              ev_pool; // pairs
+    std::vector<int>                     ev_kind; // kernel class per pair
+    size_t                               ev_used = 0;
 };
+
+enum { K_CENTRE = 0, K_SAMPLES = 1, K_RESOLVE = 2 };
+#define RT_MAX_TIMED 4096
+
+// Event pair around one launch when timing is on; returns the pair index or -1.
+static int timing_begin(RtScene* s, int kind, hipStream_t st)
+{
+    if (!s->timing || s->ev_used >= RT_MAX_TIMED) return -1;
+    if (s->ev_used * 2 + 1 >= s->ev_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return -1;
+        if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return -1;
+        }
+        s->ev_pool.push_back(a);
+        s->ev_pool.push_back(b);
+        s->ev_kind.push_back(kind);
+    }
+    const int i = (int)s->ev_used++;
+    s->ev_kind[i] = kind;
+    (void)hipEventRecord(s->ev_pool[2 * i], st);
+    return i;
+}
+static void timing_end(RtScene* s, int i, hipStream_t st)
+{
+    if (i >= 0) (void)hipEventRecord(s->ev_pool[2 * i + 1], st);
+}
 
 template <class T>
 static int upload(void** dptr, const std::vector<T>& v, size_t* total)
@@ -418,6 +451,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -604,6 +638,33 @@ extern "C" int rt_scene_info(const RtScene* s, RtSceneInfo* info)
     info->tree_depth = s->tree_depth;
     info->n_slots = s->d.n_slots;
     info->device_bytes = s->bytes;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_timing(RtScene* s, int enable)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_timing: null scene");
+    s->timing = enable != 0;
+    s->ev_used = 0;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_collect_timing(RtScene* s, RtKernelTimes* out)
+{
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_collect_timing: null argument");
+    memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < s->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]) != hipSuccess) continue;
+        switch (s->ev_kind[i]) {
+        case K_CENTRE: out->centre_ms += ms, out->centre_launches++; break;
+        case K_SAMPLES: out->samples_ms += ms, out->samples_launches++; break;
+        default: out->resolve_ms += ms, out->resolve_launches++; break;
+        }
+    }
+    s->ev_used = 0;
     return RT_OK;
 }
 
@@ -804,21 +865,29 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
     if (n_slots > 0) {
         const size_t lds = stack_bytes(s);
         if (P.msaa == 1) {
+            const int tc = timing_begin(s, K_CENTRE, stream);
             hipLaunchKernelGGL(k_centre<true>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
                                stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, (unsigned char*)nullptr,
                                s->d_ctr);
+            timing_end(s, tc, stream);
             HIP_TRY(hipGetLastError());
         } else {
+            int te = timing_begin(s, K_CENTRE, stream);
             hipLaunchKernelGGL(k_centre<false>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
                                stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, s->d_flags, s->d_ctr);
+            timing_end(s, te, stream);
             HIP_TRY(hipGetLastError());
+            te = timing_begin(s, K_SAMPLES, stream);
             hipLaunchKernelGGL(k_samples, dim3(blocks_for(n_slots * P.msaa, RT_BLOCK)), dim3(RT_BLOCK),
                                lds, stream, s->d, P, n_slots, (const unsigned char*)s->d_flags,
                                s->d_samples, s->d_ctr);
+            timing_end(s, te, stream);
             HIP_TRY(hipGetLastError());
+            te = timing_begin(s, K_RESOLVE, stream);
             hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_slots, 256)), dim3(256), 0, stream, P,
                                n_slots, (const unsigned char*)s->d_flags,
                                (const float4*)s->d_samples, d_rgb, d_depth);
+            timing_end(s, te, stream);
             HIP_TRY(hipGetLastError());
         }
     }

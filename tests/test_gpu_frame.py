@@ -1,0 +1,242 @@
+"""GPU tests of the frame-level path through the product's own host code:
+post-process kernels, tile partition, the 'r' path's files, full-size spot
+checks against the committed sparse fixtures, and error handling."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SCENES, pkg
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.float32(3.402823466e+38)
+
+
+@pytest.fixture(scope="module")
+def P():
+    return pkg()
+
+
+def _host_gpu(P, name):
+    hs = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
+    m, lights = P.host.read_camera_sav(os.path.join(SCENES, "cameras", name + ".sav"))
+    return hs, hs.to_gpu(0), m, lights
+
+
+def test_scene_info(P):
+    hs, gs, _, _ = _host_gpu(P, "final")
+    i = gs.info()
+    assert (i["n_nodes"], i["n_triangles"], i["tree_depth"], i["n_slots"]) == (891, 3846, 20, 3846)
+    assert i["device_bytes"] > 3846 * 48
+
+
+def test_normalize_depth_matches_oracle(P, oracle):
+    rng = np.random.default_rng(2)
+    d = (rng.random(100003, dtype=np.float32) * 0.9 + 0.05).astype(np.float32)
+    d[rng.integers(0, d.size, 500)] = FLT_MAX
+    for focus in (0.0, 0.37):
+        assert np.array_equal(P.capi.normalize_depth(d, focus), oracle.normalize_depth(d, focus))
+    once = P.capi.normalize_depth(d, 0.37)
+    assert np.array_equal(P.capi.normalize_depth(once, 0.37), oracle.normalize_depth(once, 0.37))
+    allmiss = np.full(10, FLT_MAX, np.float32)
+    assert (P.capi.normalize_depth(allmiss) == 0).all()
+
+
+def test_dof_blur_matches_oracle(P, oracle):
+    rng = np.random.default_rng(4)
+    W, H = 96, 70
+    rgb = rng.random((H, W, 3), dtype=np.float32)
+    dn = rng.random((H, W), dtype=np.float32)
+    dn[10:20, 10:30] = 0.0       # in focus: identity kernel
+    dn[40, 50] = 1.0             # farthest pixel: NaN kernel
+    got, ref = P.capi.dof_blur(rgb, dn), oracle.blur(rgb, dn, threads=4)
+    assert got.shape == ref.shape == (H - 12, W - 12, 3)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[34, 44]).all()
+    ok = ~np.isnan(ref)
+    assert np.abs(got[ok] - ref[ok]).max() < 2e-6        # powf differs by ulps between the two
+    assert np.array_equal(got[4:14, 4:24], rgb[10:20, 10:30])
+    q, oq = P.capi.quantize(got), oracle.to_bytes(ref)
+    assert (np.abs(q.astype(int) - oq.astype(int)) <= 1).all() and (q == oq).mean() > 0.995
+
+
+def test_quantize_matches_oracle(P, oracle):
+    v = np.float32([0, 0.999, 1.0, 0.5, np.nan, 3e9, -3e9, 1 / 255, 0.0039215684])
+    assert np.array_equal(P.capi.quantize(v), oracle.to_bytes(v))
+    r = np.random.default_rng(1).random(10000, dtype=np.float32)
+    assert np.array_equal(P.capi.quantize(r), oracle.to_bytes(r))
+
+
+def test_tiles_on_device_match_numpy(P):
+    import torch
+    W, H, tw, th, world = 100, 70, 16, 8, 3
+    rng = np.random.default_rng(9)
+    rgb = rng.random((H, W, 3), dtype=np.float32)
+    depth = rng.random((H, W), dtype=np.float32)
+    d_rgb, d_depth = torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda()
+    out_rgb, out_depth = torch.zeros_like(d_rgb), torch.zeros_like(d_depth)
+    L = P.capi.lib()
+    p = P.capi.default_params(W, H)
+    p.tile_w, p.tile_h, p.world = tw, th, world
+    for r in range(world):
+        p.rank = r
+        n = L.rt_tile_pixels(C.byref(p), r)
+        pay = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        P.capi.check(L.rt_pack_tiles_device(0, C.byref(p), d_rgb.data_ptr(), d_depth.data_ptr(),
+                                            pay.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(pay.cpu().numpy(), P.tiles.pack(rgb, depth, tw, th, r, world))
+        P.capi.check(L.rt_unpack_tiles_device(0, C.byref(p), r, pay.data_ptr(), out_rgb.data_ptr(),
+                                              out_depth.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out_rgb.cpu().numpy(), rgb) and np.array_equal(out_depth.cpu().numpy(), depth)
+
+
+@pytest.mark.parametrize("name,msaa", [("refractionballs", 1), ("final", 4)])
+def test_partitioned_render_equals_whole_frame(P, name, msaa):
+    """Two ranks' tiles rendered one after the other into one frame buffer."""
+    import torch
+    hs, gs, m, lights = _host_gpu(P, name)
+    W, H = 200, 120
+    corners = P.host.camera_corners(m, W, H)
+    whole = gs.render(corners, lights, P.capi.default_params(W, H, msaa))
+    rgb = torch.zeros((H, W, 3), device="cuda")
+    depth = torch.zeros((H, W), device="cuda")
+    tri = torch.full((H, W), -7, dtype=torch.int32, device="cuda")
+    rays = 0
+    for r in range(2):
+        p = P.capi.default_params(W, H, msaa)
+        p.tile_w, p.tile_h, p.rank, p.world = 32, 16, r, 2
+        st = gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), tri.data_ptr(),
+                              0, stats=True)
+        rays += st.rays_closest + st.rays_shadow
+        if r == 0:
+            assert (tri.cpu().numpy() == -7).sum() > 0      # the other rank's pixels untouched
+    assert np.array_equal(rgb.cpu().numpy(), whole[0]) and np.array_equal(depth.cpu().numpy(), whole[1])
+    assert np.array_equal(tri.cpu().numpy(), whole[2])
+    assert rays == whole[3].rays_closest + whole[3].rays_shadow
+
+
+def test_r_path_files_match_oracle_writers(P, oracle, tmp_path):
+    """rt_render's path: init() + camera.sav + doDaRayTracingShizz -> four files."""
+    name, W, H, msaa = "final", 160, 100, 4
+    obj, sav = os.path.join(SCENES, name + ".obj"), os.path.join(SCENES, "cameras", name + ".sav")
+    secs, st = P.host.render_to_files(obj, sav, W, H, msaa, str(tmp_path))
+    assert secs > 0 and st.rays_closest > 0
+    s = oracle.Scene.load(obj)
+    m, lights = oracle.read_camera_sav(sav)
+    s.set_lights(lights)
+    s.settings.MSAA = msaa
+    rgb, depth, _ = s.render(oracle.camera_corners(m, W, H), W, H, threads=8)
+    L = oracle.lib()
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    L.or_write_ppm(str(ref / "result.ppm").encode(), rgb.reshape(-1), W, H)
+    L.or_write_bmp(str(ref / "result.bmp").encode(), rgb.reshape(-1), W, H)
+    dn = oracle.normalize_depth(depth)
+    L.or_write_depth_bmp(str(ref / "depth.bmp").encode(), None, dn.reshape(-1), W, H)
+    dn = oracle.normalize_depth(dn)
+    blur = oracle.blur(rgb, dn, threads=8)
+    L.or_write_blurred_bmp(str(ref / "blurred.bmp").encode(), blur.reshape(-1), W, H)
+    for f in ("result.ppm", "result.bmp", "depth.bmp", "blurred.bmp"):
+        a = np.frombuffer((tmp_path / f).read_bytes(), np.uint8)
+        b = np.frombuffer((ref / f).read_bytes(), np.uint8)
+        assert a.size == b.size, f
+        hdr = 54 if f.endswith(".bmp") else 15
+        assert np.array_equal(a[:hdr], b[:hdr]), f
+        d = np.abs(a[hdr:].astype(int) - b[hdr:].astype(int))
+        assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.99, (f, d.max(), (d > 1).sum())
+
+
+FC = json.load(open(os.path.join(GOLDEN, "frame_counters.json"))) \
+    if os.path.exists(os.path.join(GOLDEN, "frame_counters.json")) else {}
+
+
+@pytest.mark.parametrize("key", sorted(FC))
+def test_full_size_frames_against_sparse_fixture(P, oracle, key):
+    """BASELINE's configs at full size: 20000 seeded pixels of the oracle's frame."""
+    cfg = FC[key]
+    g = np.load(os.path.join(GOLDEN, f"sparse_{key}.npz"))
+    hs, gs, m, lights = _host_gpu(P, cfg["scene"])
+    W, H = cfg["width"], cfg["height"]
+    corners = P.host.camera_corners(m, W, H)
+    assert np.allclose(corners, g["corners"], rtol=0, atol=2e-6)
+    rgb, depth, tri, st = gs.render(g["corners"], g["lights"], P.capi.default_params(W, H, cfg["msaa"]))
+    x, y = g["x"], g["y"]
+    assert (tri[y, x] == g["tri"]).mean() >= 0.9999
+    q = oracle.to_bytes(rgb[y, x])
+    d = np.abs(q.astype(int) - g["rgb8"].astype(int)).max(axis=1)
+    assert (d <= 1).mean() >= 0.999, f"{(d > 1).sum()} of {d.size} sampled pixels off by > 1 LSB"
+    miss = g["depth"] == FLT_MAX
+    assert ((depth[y, x] == FLT_MAX) == miss).mean() >= 0.9999
+    both = ~miss & (depth[y, x] != FLT_MAX)
+    assert (np.abs(depth[y, x][both] - g["depth"][both]) <= 1e-5 * g["depth"][both]).mean() >= 0.9995
+    # size-independent properties of the whole frame
+    assert abs((tri >= 0).mean() - cfg["hit_fraction"]) < 1e-4
+    assert (rgb >= 0).all() and (rgb <= 1).all()                 # RGBValue clamp
+    assert (rgb[tri < 0] == np.float32([0.2, 0.5, 1.0])).all()    # misses are background
+    assert (depth[tri < 0] == FLT_MAX).all()
+    # the GPU skips the discarded centre-ray subtrees and traces shadows any-hit:
+    # fewer queries than the reference's count, never more
+    ref_rays = cfg["frame"]["rays_closest"] + cfg["frame"]["rays_shadow"]
+    gpu_rays = st.rays_closest + st.rays_shadow
+    assert gpu_rays <= ref_rays
+    if cfg["msaa"] == 1:
+        assert gpu_rays >= 0.95 * ref_rays
+
+
+def test_bad_arguments_are_rejected(P):
+    hs, gs, m, lights = _host_gpu(P, "ball")
+    L = P.capi.lib()
+    corners = P.host.camera_corners(m, 64, 64)
+    p = P.capi.default_params(64, 64)
+    p.msaa = 3
+    with pytest.raises(P.capi.RtError, match="msaa"):
+        gs.render(corners, lights, p)
+    p = P.capi.default_params(1, 64)
+    with pytest.raises(P.capi.RtError, match="frame size"):
+        gs.render(corners, lights, p)
+    with pytest.raises(P.capi.RtError, match="n_lights"):
+        gs.trace_rays(np.zeros((1, 3)), np.ones((1, 3)), np.zeros((65, 3), np.float32))
+    with pytest.raises(P.capi.RtError, match="k "):
+        gs.trace_rays(np.zeros((1, 3)), np.ones((1, 3)), lights, k=6)
+    with pytest.raises(P.capi.RtError, match="13x13"):
+        P.capi.dof_blur(np.zeros((10, 10, 3), np.float32), np.zeros((10, 10), np.float32))
+    # a scene whose node list points outside the triangle array
+    a = hs.arrays()
+    bad = a["node_tris"].copy()
+    bad[0] = 10 ** 6
+    with pytest.raises(P.capi.RtError, match="lists triangle"):
+        P.capi.Scene(a["vertex_pos"], a["vertex_normal"], a["tri_vertex"], a["tri_texcoord"],
+                     a["tri_material"], a["texcoords"], a["materials"], a["textures"],
+                     a["node_bounds"], a["node_left"], a["node_right"], a["node_tri_off"],
+                     a["node_tri_cnt"], bad)
+    # zero rays and zero lights are fine
+    rgb, mt, tri, _ = gs.trace_rays(np.zeros((0, 3)), np.zeros((0, 3)), lights)
+    assert rgb.shape == (0, 3)
+    rgb, _, _, _ = gs.trace_rays([[0, 1.6, 3.6]], [[0, 0.45, 0]], np.zeros((0, 3), np.float32))
+    assert np.isfinite(rgb).all()
+
+
+def test_trace_rays_k_and_prev_ni(P, oracle):
+    """performRayTracing's k and prev_Ni arguments (raytracing.cpp:61,166-175)."""
+    s = oracle.Scene.load(os.path.join(SCENES, "refractionballs.obj"))
+    g = np.load(os.path.join(GOLDEN, "refractionballs.npz"))
+    s.set_lights(g["lights"])
+    from conftest import gpu_scene_from_oracle
+    gs = gpu_scene_from_oracle(s)
+    o, d = g["origins"][:3000], g["dests"][:3000]
+    full, _, _, _ = gs.trace_rays(o, d, g["lights"], k=0)
+    last, _, _, st = gs.trace_rays(o, d, g["lights"], k=4)
+    assert st.rays_closest == len(o)                     # k = 4 spawns no children
+    assert not np.array_equal(full, last)
+    L = oracle.lib()
+    ref = np.zeros((len(o), 3), np.float32)
+    mt = C.c_float()
+    for i in range(0, len(o), 37):
+        L.or_perform_ray_tracing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.or_perform_ray_tracing(s.h, o[i].ctypes.data, d[i].ctypes.data, 4, 1.0, C.byref(mt),
+                                 ref[i].ctypes.data, None)
+        assert np.abs(ref[i] - last[i]).max() < 1e-5
