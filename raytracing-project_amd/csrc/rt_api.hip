@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -386,6 +387,7 @@ struct RtScene {
     void*   d_mats = nullptr;
     void*   d_texinfo = nullptr;
     void*   d_texels = nullptr;
+    void*   d_rank = nullptr;
     int     tree_depth = 0;
     size_t  bytes = 0;
     // per-call workspace, grown on demand
@@ -446,7 +448,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -523,9 +525,107 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     if (max_depth + 1 > 64)
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: KD tree depth %d exceeds 63", max_depth);
 
+    // ---- triangle lists per node ----
+    // own[k]: the node's AccelTreeNode::triangles.  rank[t]: position of triangle t in the
+    // order "nodes breadth first, list order inside a node"; on one root-to-leaf path that is
+    // the order the reference's walk tests triangles in (raytracing.cpp:311-338), so among
+    // hits with equal t the larger rank is the one the reference ends up with.
+    std::vector<std::vector<int>> lists(order.size());
+    std::vector<int>              rank((size_t)std::max(nt, 1), 0);
+    {
+        int r = 0;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const RtKdNode& n = desc->nodes[order[k]];
+            for (int i = 0; i < n.tri_count; ++i) {
+                const int t = desc->node_tris[n.tri_offset + i];
+                if (t < 0 || t >= nt)
+                    return fail(RT_ERR_INVALID, "rt_scene_create: node %d lists triangle %d", order[k], t);
+                lists[k].push_back(t);
+                rank[t] = r++;
+            }
+        }
+    }
+    // Triangles the reference keeps in inner nodes (those touching the node's split plane,
+    // KDtree.cpp:136-152) are handed down to every leaf whose cell they overlap, so that a
+    // ray only meets triangles of the cells it crosses.  The closest hit over all triangles
+    // is unchanged; ties are settled by rank, not by test order.  RT_KD_PUSHDOWN=0 keeps the
+    // reference's placement (for A/B timing).
+    const char* pd_env = getenv("RT_KD_PUSHDOWN");
+    const bool  pushdown = !(pd_env && pd_env[0] == '0');
+    if (pushdown && nn > 0 && nt > 0) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int v = 0; v < nv; ++v)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], (double)desc->vertex_pos[3 * v + a]);
+                hi[a] = std::max(hi[a], (double)desc->vertex_pos[3 * v + a]);
+            }
+        struct Box {
+            double lo[3], hi[3];
+        };
+        std::vector<Box> cell(order.size());
+        for (int a = 0; a < 3; ++a) { // outer cells are open: stand-in far beyond the mesh
+            const double ext = hi[a] - lo[a] + 10.0;
+            cell[0].lo[a] = lo[a] - ext, cell[0].hi[a] = hi[a] + ext;
+        }
+        auto overlaps = [&](int t, const Box& b) -> bool {
+            // separating-axis test triangle vs box, box grown a little: conservative
+            double c[3], h[3], v[3][3];
+            for (int a = 0; a < 3; ++a) {
+                c[a] = 0.5 * (b.lo[a] + b.hi[a]);
+                h[a] = 0.5 * (b.hi[a] - b.lo[a]);
+                h[a] += 1e-5 * std::fabs(h[a]) + 1e-5 * (std::fabs(c[a]) + 1.0);
+            }
+            for (int j = 0; j < 3; ++j)
+                for (int a = 0; a < 3; ++a)
+                    v[j][a] = (double)desc->vertex_pos[3 * desc->tri_vertex[3 * t + j] + a] - c[a];
+            for (int a = 0; a < 3; ++a) {
+                const double mn = std::min(v[0][a], std::min(v[1][a], v[2][a]));
+                const double mx = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+                if (mn > h[a] || mx < -h[a]) return false;
+            }
+            double e[3][3];
+            for (int a = 0; a < 3; ++a) {
+                e[0][a] = v[1][a] - v[0][a];
+                e[1][a] = v[2][a] - v[1][a];
+                e[2][a] = v[0][a] - v[2][a];
+            }
+            for (int i = 0; i < 3; ++i)
+                for (int a = 0; a < 3; ++a) { // axis = unit(a) x e[i]
+                    double ax[3] = {0, 0, 0};
+                    const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+                    ax[a1] = -e[i][a2], ax[a2] = e[i][a1];
+                    const double p0 = ax[0] * v[0][0] + ax[1] * v[0][1] + ax[2] * v[0][2];
+                    const double p1 = ax[0] * v[1][0] + ax[1] * v[1][1] + ax[2] * v[1][2];
+                    const double p2 = ax[0] * v[2][0] + ax[1] * v[2][1] + ax[2] * v[2][2];
+                    const double r = h[0] * std::fabs(ax[0]) + h[1] * std::fabs(ax[1]) + h[2] * std::fabs(ax[2]);
+                    const double mn = std::min(p0, std::min(p1, p2)), mx = std::max(p0, std::max(p1, p2));
+                    const double slack = 1e-9 * (r + std::fabs(mn) + std::fabs(mx)) + 1e-300;
+                    if (mn > r + slack || mx < -r - slack) return false;
+                }
+            double nrm[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                             e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+            const double d = nrm[0] * v[0][0] + nrm[1] * v[0][1] + nrm[2] * v[0][2];
+            const double r = h[0] * std::fabs(nrm[0]) + h[1] * std::fabs(nrm[1]) + h[2] * std::fabs(nrm[2]);
+            return std::fabs(d) <= r + 1e-9 * (r + std::fabs(d));
+        };
+        for (size_t k = 0; k < order.size(); ++k) {
+            if (new_left[k] < 0) continue;
+            const int    axis = depth_of[k] % 3;
+            const int    l = new_left[k], r = l + 1;
+            const double plane = desc->nodes[desc->nodes[order[k]].left].bounds[2 * axis + 1];
+            cell[l] = cell[k], cell[r] = cell[k];
+            cell[l].hi[axis] = plane, cell[r].lo[axis] = plane;
+            for (int t : lists[k]) {
+                const bool inl = overlaps(t, cell[l]), inr = overlaps(t, cell[r]);
+                if (inl || !inr) lists[l].push_back(t);
+                if (inr || !inl) lists[r].push_back(t);
+            }
+            lists[k].clear();
+        }
+    }
+
     std::vector<DNode>  nodes(order.size());
     std::vector<float4> slots;
-    slots.reserve((size_t)nnt * 3);
     for (size_t k = 0; k < order.size(); ++k) {
         const RtKdNode& n = desc->nodes[order[k]];
         DNode           dn;
@@ -533,11 +633,10 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         dn.left = new_left[k];
         dn.split = dn.left >= 0 ? desc->nodes[n.left].bounds[2 * axis + 1] : 0.0f;
         dn.tri_off = (int)(slots.size() / 3);
-        dn.cnt_axis = n.tri_count | (axis << 28);
-        for (int i = 0; i < n.tri_count; ++i) {
-            const int t = desc->node_tris[n.tri_offset + i];
-            if (t < 0 || t >= nt)
-                return fail(RT_ERR_INVALID, "rt_scene_create: node %d lists triangle %d", order[k], t);
+        if (lists[k].size() >= (1u << 28))
+            return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: node triangle list too long");
+        dn.cnt_axis = (int)lists[k].size() | (axis << 28);
+        for (int t : lists[k]) {
             const float* v0 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t];
             const float* v1 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t + 1];
             const float* v2 = desc->vertex_pos + 3 * desc->tri_vertex[3 * t + 2];
@@ -553,6 +652,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         }
         nodes[k] = dn;
     }
+    if (slots.size() / 3 >= (1u << 30))
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many triangle references");
 
     std::vector<float4> shade((size_t)nt * 3);
     std::vector<int4>   info((size_t)nt);
@@ -603,7 +704,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
         (rc = upload(&s->d_texcoords, texcoords, &s->bytes)) ||
         (rc = upload(&s->d_mats, mats, &s->bytes)) || (rc = upload(&s->d_texinfo, texinfo, &s->bytes)) ||
-        (rc = upload(&s->d_texels, texels, &s->bytes))) {
+        (rc = upload(&s->d_texels, texels, &s->bytes)) || (rc = upload(&s->d_rank, rank, &s->bytes))) {
         rt_scene_destroy(s);
         return rc;
     }
@@ -622,6 +723,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.mats = (const float4*)s->d_mats;
     s->d.tex_info = (const int4*)s->d_texinfo;
     s->d.texels = (const uint8_t*)s->d_texels;
+    s->d.tri_rank = (const int32_t*)s->d_rank;
     s->d.n_nodes = (int)nodes.size();
     s->d.n_slots = (int)(slots.size() / 3);
     s->d.n_triangles = nt;

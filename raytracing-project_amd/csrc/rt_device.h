@@ -30,10 +30,10 @@ struct DNode {
     int32_t cnt_axis; // triangle count | axis << 28
 };
 
-// Triangle slots follow node order (breadth first), ascending inside a node,
-// so a larger slot index = tested later by the reference's walk on the same
-// root-to-leaf path (raytracing.cpp:311-338): ties in t go to the larger slot.
-// Three float4 per slot:
+// Triangle slots: every node's list in node order; a triangle may be listed by
+// several leaves.  Ties in t go to the triangle the reference's walk would have
+// tested last on its root-to-leaf path (raytracing.cpp:311-338), recorded per
+// triangle in DScene::tri_rank.  Three float4 per slot:
 //   q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
 //   q1 = e2.y e2.z v2.x v2.y
 //   q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
@@ -46,6 +46,7 @@ struct DScene {
     const float4*  mats;      // 4 float4 per material: Kd.xyz Ns | Ks.xyz Ni | illum has_Ni tex _ | pad
     const int4*    tex_info;  // per texture: byte offset, width, height, 0
     const uint8_t* texels;
+    const int32_t* tri_rank;  // per original triangle: order in which the reference's walk tests it
     int32_t        n_nodes, n_slots, n_triangles, stack_entries;
 };
 
@@ -154,7 +155,12 @@ __device__ __forceinline__ bool kd_trace(const DScene& S, f3 o, f3 dst, uint2* s
             ++n_tests;
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
-                if (t != minT || slot > h.slot) h.slot = slot, h.a = a, h.b = b, minT = t;
+                bool take = t != minT || h.slot < 0;
+                if (!take) { // equal t: keep the one the reference's test order ends with
+                    const int cur = __float_as_int(S.tris[3 * h.slot + 2].w);
+                    take = S.tri_rank[__float_as_int(q2.w)] > S.tri_rank[cur];
+                }
+                if (take) h.slot = slot, h.a = a, h.b = b, minT = t;
             }
         }
         if (nd.left >= 0) {

@@ -28,7 +28,8 @@ def _host_gpu(P, name):
 def test_scene_info(P):
     hs, gs, _, _ = _host_gpu(P, "final")
     i = gs.info()
-    assert (i["n_nodes"], i["n_triangles"], i["tree_depth"], i["n_slots"]) == (891, 3846, 20, 3846)
+    assert (i["n_nodes"], i["n_triangles"], i["tree_depth"]) == (891, 3846, 20)
+    assert i["n_slots"] >= 3846          # straddling triangles are listed by every leaf they touch
     assert i["device_bytes"] > 3846 * 48
 
 

@@ -1,0 +1,18 @@
+"""One-config render loop for profiling: python tools/prof_frame.py <scene> <W> <H> <msaa> [frames]"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("raytracing-project_amd")
+capi, host = pkg.capi, pkg.host
+name, W, H, msaa = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+frames = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+hs = host.HostScene(os.path.join(ROOT, "scenes", name + ".obj"))
+gs = hs.to_gpu(0)
+m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
+corners = host.camera_corners(m, W, H)
+p = capi.default_params(W, H, msaa)
+for _ in range(frames):
+    rgb, depth, tri, st = gs.render(corners, lights, p)
+rays = st.rays_closest + st.rays_shadow
+print(f"{name} {W}x{H} msaa{msaa}: {st.kernel_ms:.2f} ms, {rays/1e6:.1f} Mrays, {rays/st.kernel_ms/1e3:.0f} Mrays/s, "
+      f"tests/ray {st.tri_tests/rays:.1f}, nodes/ray {st.node_visits/rays:.1f}, slots {gs.info()['n_slots']}")
