@@ -114,6 +114,10 @@ typedef struct RtStats {
     float    reserved;
 } RtStats;
 
+/* The scene as laid out on the device: the reference's tree with its inner-node
+ * triangles handed down to the leaves and large leaves split further, so
+ * n_nodes / tree_depth can exceed the input's; n_slots counts triangle
+ * references (a triangle is listed by every leaf it touches). */
 typedef struct RtSceneInfo {
     int32_t  n_nodes, n_triangles, tree_depth, n_slots;
     uint64_t device_bytes;

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
+# RT_HIP_LIB selects another build of the library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "csrc", "librt_hip.so")
 
 RT_MAX_LIGHTS = 64
 

@@ -194,6 +194,8 @@ __constant__ float c_msaa16[16][2] = {
     {-15.f / 32, 9.f / 32},  {-7.f / 32, 11.f / 32},  {1.f / 32, 13.f / 32},  {9.f / 32, 15.f / 32}};
 // main.cpp:469-500 (all offsets are exact binary fractions)
 
+#include "rt_wavefront.h"
+
 // One thread per (sample, pixel slot) of the pixels whose centre ray hit.
 // samples[(slot * msaa + s)] = r g b minT.
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -397,6 +399,15 @@ struct RtScene {
     float4*        d_samples = nullptr;
     size_t         samples_cap = 0;
     hipEvent_t     ev0 = nullptr, ev1 = nullptr;
+    // wavefront renderer
+    bool       pushdown = false;   // inner nodes carry no triangles
+    bool       refractive = false; // some material can spawn two child rays
+    int        wf_grid_trace = 0, wf_grid_any = 0;
+    size_t     wf_lds = 0;
+    int        wf_nodes_in_lds = 0;
+    void*      wf_mem = nullptr;   // one allocation carved into the queues
+    void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
+    size_t     wf_mem_bytes = 0;
     // optional per-kernel timing (rt_scene_set_timing)
     bool                                 timing = false;
     std::vector<hipEvent_t>              ev_pool; // pairs
@@ -448,7 +459,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -552,6 +563,15 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     // reference's placement (for A/B timing).
     const char* pd_env = getenv("RT_KD_PUSHDOWN");
     const bool  pushdown = !(pd_env && pd_env[0] == '0');
+    // per node: split axis and plane (leaves: unused).  The reference cycles x, y, z with
+    // the depth (KDtree.cpp:75-133) and the plane is the left child's end on that axis.
+    std::vector<int>   axis_of(order.size(), 0);
+    std::vector<float> split_of(order.size(), 0.0f);
+    for (size_t k = 0; k < order.size(); ++k) {
+        axis_of[k] = depth_of[k] % 3;
+        if (new_left[k] >= 0)
+            split_of[k] = desc->nodes[desc->nodes[order[k]].left].bounds[2 * axis_of[k] + 1];
+    }
     if (pushdown && nn > 0 && nt > 0) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int v = 0; v < nv; ++v)
@@ -622,16 +642,105 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             }
             lists[k].clear();
         }
+        // Leaves that ended up with many triangles are split further (surface-area
+        // heuristic over the triangles' bounds inside the cell).  The planes of the
+        // reference's tree stay; this only adds levels below its leaves, and the
+        // closest hit over all triangles does not depend on how they are grouped.
+        // RT_KD_REFINE=0 switches it off.
+        const char* rf_env = getenv("RT_KD_REFINE");
+        if (!(rf_env && rf_env[0] == '0')) {
+            const int    leaf_target = 4;       // do not split leaves at or below this size
+            const double c_trav = 1.0, c_isect = 3.0;
+            const size_t max_nodes = 60000;     // node indices are 16-bit on the traversal stack
+            Box          mesh_box;
+            for (int a = 0; a < 3; ++a) {
+                const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
+                mesh_box.lo[a] = lo[a] - pad, mesh_box.hi[a] = hi[a] + pad;
+            }
+            auto area = [](const Box& b) {
+                const double dx = std::max(b.hi[0] - b.lo[0], 0.0), dy = std::max(b.hi[1] - b.lo[1], 0.0),
+                             dz = std::max(b.hi[2] - b.lo[2], 0.0);
+                return 2.0 * (dx * dy + dy * dz + dz * dx);
+            };
+            for (size_t k = 0; k < lists.size() && lists.size() + 2 <= max_nodes; ++k) {
+                if (new_left[k] >= 0 || (int)lists[k].size() <= leaf_target || depth_of[k] >= 60) continue;
+                Box cb = cell[k]; // the part of the cell rays can come from
+                for (int a = 0; a < 3; ++a) {
+                    cb.lo[a] = std::max(cb.lo[a], mesh_box.lo[a]);
+                    cb.hi[a] = std::min(cb.hi[a], mesh_box.hi[a]);
+                }
+                const double sa = area(cb);
+                if (!(sa > 0.0)) continue;
+                const size_t n = lists[k].size();
+                double       best_cost = c_isect * (double)n;
+                int          best_axis = -1;
+                double       best_plane = 0.0;
+                std::vector<double> mins(n), maxs(n), cand;
+                for (int a = 0; a < 3; ++a) {
+                    cand.clear();
+                    for (size_t i = 0; i < n; ++i) {
+                        const int t = lists[k][i];
+                        double    mn = 1e300, mx = -1e300;
+                        for (int j = 0; j < 3; ++j) {
+                            const double c = desc->vertex_pos[3 * desc->tri_vertex[3 * t + j] + a];
+                            mn = std::min(mn, c), mx = std::max(mx, c);
+                        }
+                        mins[i] = mn, maxs[i] = mx;
+                        if (mn > cb.lo[a] && mn < cb.hi[a]) cand.push_back(mn);
+                        if (mx > cb.lo[a] && mx < cb.hi[a]) cand.push_back(mx);
+                    }
+                    for (double pl : cand) {
+                        const float plf = (float)pl; // the plane the kernel will compare against
+                        if (!((double)plf > cb.lo[a] && (double)plf < cb.hi[a])) continue;
+                        size_t nl = 0, nr = 0;
+                        for (size_t i = 0; i < n; ++i) {
+                            if (mins[i] < (double)plf || (mins[i] == (double)plf && maxs[i] == (double)plf)) ++nl;
+                            if (maxs[i] > (double)plf) ++nr;
+                        }
+                        Box bl = cb, br = cb;
+                        bl.hi[a] = plf, br.lo[a] = plf;
+                        double cost = c_trav + c_isect * (area(bl) * (double)nl + area(br) * (double)nr) / sa;
+                        if (nl == 0 || nr == 0) cost *= 0.8;
+                        if (cost < best_cost) best_cost = cost, best_axis = a, best_plane = (double)plf;
+                    }
+                }
+                if (best_axis < 0) continue;
+                Box bl = cell[k], br = cell[k];
+                bl.hi[best_axis] = best_plane, br.lo[best_axis] = best_plane;
+                std::vector<int> ll, rr;
+                for (int t : lists[k]) {
+                    const bool inl = overlaps(t, bl), inr = overlaps(t, br);
+                    if (inl || !inr) ll.push_back(t);
+                    if (inr || !inl) rr.push_back(t);
+                }
+                if (ll.size() == n && rr.size() == n) continue; // nothing separated
+                const int l = (int)lists.size();
+                new_left[k] = l;
+                axis_of[k] = best_axis;
+                split_of[k] = (float)best_plane;
+                for (int c = 0; c < 2; ++c) {
+                    new_left.push_back(-1);
+                    depth_of.push_back(depth_of[k] + 1);
+                    axis_of.push_back(0);
+                    split_of.push_back(0.0f);
+                    cell.push_back(c == 0 ? bl : br);
+                    lists.push_back(c == 0 ? ll : rr);
+                }
+                max_depth = std::max(max_depth, depth_of[k] + 1);
+                lists[k].clear();
+            }
+        }
     }
+    if (max_depth + 1 > 64)
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: KD tree depth %d exceeds 63", max_depth);
 
-    std::vector<DNode>  nodes(order.size());
+    std::vector<DNode>  nodes(lists.size());
     std::vector<float4> slots;
-    for (size_t k = 0; k < order.size(); ++k) {
-        const RtKdNode& n = desc->nodes[order[k]];
-        DNode           dn;
-        const int       axis = depth_of[k] % 3; // KDtree.cpp:75-133 cycles x,y,z with depth
+    for (size_t k = 0; k < lists.size(); ++k) {
+        DNode     dn;
+        const int axis = axis_of[k];
         dn.left = new_left[k];
-        dn.split = dn.left >= 0 ? desc->nodes[n.left].bounds[2 * axis + 1] : 0.0f;
+        dn.split = dn.left >= 0 ? split_of[k] : 0.0f;
         dn.tri_off = (int)(slots.size() / 3);
         if (lists[k].size() >= (1u << 28))
             return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: node triangle list too long");
@@ -728,6 +837,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.n_slots = (int)(slots.size() / 3);
     s->d.n_triangles = nt;
     s->d.stack_entries = max_depth + 1;
+    s->pushdown = pushdown;
+    for (int i = 0; i < nm; ++i) // raytracing.cpp:177,206: two children only if Ni > 1 and not a mirror
+        if (desc->materials[i].Ni > 1.0f && desc->materials[i].illum != 3) s->refractive = true;
     *out = s;
     return RT_OK;
 }
@@ -947,6 +1059,180 @@ static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
     return RT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// wavefront renderer (rt_wavefront.h)
+// ---------------------------------------------------------------------------
+#define WF_WORKSPACE_BUDGET ((size_t)12 << 30) // bytes of queues per scene at most
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int wf_prepare(RtScene* s)
+{
+    if (s->wf_grid_trace) return RT_OK;
+    // LDS per block: the top of the node array + the traversal stacks, kept near 40 KB so
+    // that four blocks fit a CU
+    const size_t stack_bytes_ = (size_t)s->d.stack_entries * WF_BLOCK * sizeof(unsigned short);
+    const char*  lds_env = getenv("RT_WF_LDS_KB");
+    const size_t budget = (size_t)(lds_env ? atoi(lds_env) : 40) * 1024;
+    size_t       n_lds = stack_bytes_ < budget ? (budget - stack_bytes_) / sizeof(DNode) : 0;
+    n_lds = std::min<size_t>(n_lds, (size_t)s->d.n_nodes);
+    s->wf_nodes_in_lds = (int)n_lds;
+    s->wf_lds = n_lds * sizeof(DNode) + stack_bytes_;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<false>, WF_BLOCK, s->wf_lds));
+    s->wf_grid_trace = std::max(1, per_cu) * prop.multiProcessorCount;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<true>, WF_BLOCK, s->wf_lds));
+    s->wf_grid_any = std::max(1, per_cu) * prop.multiProcessorCount;
+    return RT_OK;
+}
+
+struct WfPlan {
+    long long chunk_slots; // pixel slots per chunk (a multiple of WF_REGION_SLOTS)
+    int       G, R;        // regions per chunk, ray slots per region
+    int       n_samples;   // samples per chunk
+};
+
+static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots)
+{
+    // rays of one level per camera sample: 1 along mirror chains, up to 2^4 with refraction
+    // (levels k = 0..4 spawn, raytracing.cpp:166-168)
+    const int       growth = s->refractive ? 16 : 1;
+    const int       L = std::max(P.n_lights, 1);
+    const long long R = (long long)WF_REGION_SLOTS * P.msaa * growth;
+    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8) + 16 + 4 + (size_t)L * 17) +
+                              (size_t)WF_REGION_SLOTS * P.msaa * (3 * 8 + 4 + 4) + WF_REGION_SLOTS +
+                              (size_t)(2 + 2 * (1 + L)) * 4;
+    long long g_max = (long long)(WF_WORKSPACE_BUDGET / per_region);
+    g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
+    g_max = std::max<long long>(g_max, 1);
+    const long long g_need = (n_slots + WF_REGION_SLOTS - 1) / WF_REGION_SLOTS;
+    WfPlan          pl;
+    pl.G = (int)std::min(g_need, g_max);
+    pl.R = (int)R;
+    pl.chunk_slots = (long long)pl.G * WF_REGION_SLOTS;
+    pl.n_samples = (int)(pl.chunk_slots * P.msaa);
+    return pl;
+}
+
+static int wf_carve(RtScene* s, const WfPlan& pl, int L, WfBuffers* B, unsigned char** centre_flags)
+{
+    const size_t cap = (size_t)pl.G * pl.R, ns = (size_t)pl.n_samples, G = (size_t)pl.G;
+    size_t       need = 0;
+    size_t       off[24];
+    int          k = 0;
+    auto         take = [&](size_t bytes) {
+        off[k++] = need;
+        need += align256(bytes);
+    };
+    for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 8), take(G * 4); // 0..7
+    take(cap * 16);                            // 8 hits
+    take(cap * 4);                             // 9 wlocal
+    take(cap * 16 * (size_t)L);                // 10 sh_org
+    take(G * 4 * (size_t)L);                   // 11 sh_cnt
+    take(cap * (size_t)L);                     // 12 occl
+    take(((G + 1) + (G * (size_t)L + 1)) * 4); // 13 prefix
+    take(ns * 8 * 3);                          // 14 acc
+    take(ns * 4);                              // 15 s_minT
+    take(ns * 4);                              // 16 s_tri
+    take(sizeof(WfCounters));                  // 17
+    take((size_t)pl.chunk_slots);              // 18 centre flags
+    if (need > s->wf_mem_bytes) {
+        if (s->wf_mem) (void)hipFree(s->wf_mem);
+        s->wf_mem = nullptr, s->wf_mem_bytes = 0;
+        HIP_TRY(hipMalloc(&s->wf_mem, need));
+        s->wf_mem_bytes = need;
+    }
+    unsigned char* m = (unsigned char*)s->wf_mem;
+    for (int q = 0; q < 2; ++q) {
+        B->rays[q].o_w = (float4*)(m + off[4 * q]);
+        B->rays[q].d_ni = (float4*)(m + off[4 * q + 1]);
+        B->rays[q].meta = (uint2*)(m + off[4 * q + 2]);
+        B->rays[q].cnt = (int*)(m + off[4 * q + 3]);
+    }
+    B->hits = (float4*)(m + off[8]);
+    B->wlocal = (float*)(m + off[9]);
+    B->sh_org = (float4*)(m + off[10]);
+    B->sh_cnt = (int*)(m + off[11]);
+    B->occl = m + off[12];
+    B->prefix = (int*)(m + off[13]);
+    B->acc = (long long*)(m + off[14]);
+    B->s_minT = (float*)(m + off[15]);
+    B->s_tri = (int*)(m + off[16]);
+    B->ctr = (WfCounters*)(m + off[17]);
+    *centre_flags = m + off[18];
+    B->cap = (int)cap;
+    B->G = pl.G, B->R = pl.R;
+    B->n_samples = pl.n_samples;
+    return RT_OK;
+}
+
+static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
+                       (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
+                       (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.hits,
+                       (unsigned char*)nullptr, s->d_ctr, s->wf_nodes_in_lds);
+}
+
+static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, float* d_rgb, float* d_depth,
+                            int32_t* d_tri, hipStream_t st)
+{
+    int rc = wf_prepare(s);
+    if (rc) return rc;
+    const WfPlan   pl = wf_plan(s, P, n_slots);
+    const int      L = std::max(P.n_lights, 1);
+    WfBuffers      B;
+    unsigned char* centre_flags = nullptr;
+    if ((rc = wf_carve(s, pl, L, &B, &centre_flags))) return rc;
+    if (!s->d_params) HIP_TRY(hipMalloc(&s->d_params, sizeof(DParams)));
+    HIP_TRY(hipMemcpyAsync(s->d_params, &P, sizeof(DParams), hipMemcpyHostToDevice, st));
+    for (long long slot0 = 0; slot0 < n_slots; slot0 += pl.chunk_slots) {
+        const int n = (int)std::min<long long>(pl.chunk_slots, n_slots - slot0);
+        HIP_TRY(hipMemsetAsync(B.ctr, 0, sizeof(WfCounters), st));
+        HIP_TRY(hipMemsetAsync(B.acc, 0, (size_t)pl.n_samples * 8 * 3, st));
+        WfBuffers C = B;
+        hipLaunchKernelGGL(k_wf_gen_centre, dim3(C.G), dim3(WF_BLOCK), 0, st, P, C, slot0, n, s->d_ctr);
+        hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C, 0, 0);
+        int te = timing_begin(s, K_CENTRE, st);
+        wf_launch_trace(s, C, 0, &C.ctr->head_rays[WF_MAX_DEPTH], st);
+        timing_end(s, te, st);
+        HIP_TRY(hipGetLastError());
+        bool traced0 = true;
+        if (P.msaa > 1) {
+            hipLaunchKernelGGL(k_wf_msaa_emit, dim3(C.G), dim3(WF_BLOCK), 0, st, P, C, slot0, d_rgb, d_depth,
+                               d_tri, centre_flags, s->d_ctr);
+            std::swap(C.rays[0], C.rays[1]);
+            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C, 0, 0);
+            traced0 = false;
+        }
+        te = timing_begin(s, K_SAMPLES, st);
+        for (int level = 0; level < 5; ++level) {
+            const int q = level & 1;
+            if (level > 0 || !traced0) wf_launch_trace(s, C, q, &C.ctr->head_rays[level], st);
+            hipLaunchKernelGGL(k_wf_shade, dim3(C.G), dim3(WF_BLOCK), 0, st, s->d, P, C, level);
+            // work lists of the next level's rays (block 0) and of this level's shadow queues
+            hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, C, q ^ 1,
+                               P.n_lights);
+            if (P.n_lights > 0)
+                hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st,
+                                   s->d, (const float4*)C.sh_org, (const float4*)nullptr,
+                                   (const DParams*)s->d_params, (const int*)C.sh_cnt,
+                                   (const int*)(C.prefix + (C.G + 1)), C.G, P.n_lights * C.G, C.R, C.cap,
+                                   &C.ctr->head_shadow[level][0], (float4*)nullptr, C.occl, s->d_ctr,
+                                   s->wf_nodes_in_lds);
+            hipLaunchKernelGGL(k_wf_resolve, dim3(C.G), dim3(WF_BLOCK), 0, st, s->d, P, C, level);
+            HIP_TRY(hipGetLastError());
+        }
+        timing_end(s, te, st);
+        hipLaunchKernelGGL(k_wf_finalize, dim3(blocks_for(n, WF_BLOCK)), dim3(WF_BLOCK), 0, st, P, C, slot0, n,
+                           (const unsigned char*)centre_flags, d_rgb, d_depth, d_tri);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
 extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const float* lights,
                                       int32_t n_lights, const RtParams* params, float* d_rgb,
                                       float* d_depth, int32_t* d_tri, void* stream_, RtStats* stats)
@@ -961,10 +1247,14 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
     HIP_TRY(hipSetDevice(s->device));
     const long long n_slots = (long long)P.n_my_tiles * P.tile_w * P.tile_h;
     if (stats) memset(stats, 0, sizeof *stats);
-    if ((rc = ensure_workspace(s, n_slots, P.msaa))) return rc;
     HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (n_slots > 0) {
+    const char* mk_env = getenv("RT_MEGAKERNEL");
+    const bool  wavefront = s->pushdown && s->d.n_nodes < 65536 && !(mk_env && mk_env[0] == '1');
+    if (n_slots > 0 && wavefront) {
+        if ((rc = render_wavefront(s, P, n_slots, d_rgb, d_depth, d_tri, stream))) return rc;
+    } else if (n_slots > 0) {
+        if ((rc = ensure_workspace(s, n_slots, P.msaa))) return rc;
         const size_t lds = stack_bytes(s);
         if (P.msaa == 1) {
             const int tc = timing_begin(s, K_CENTRE, stream);

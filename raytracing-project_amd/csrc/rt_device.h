@@ -68,7 +68,7 @@ struct DCounters {
 struct f3 {
     float x, y, z;
 };
-__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__host__ __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 // Vec3D.h:12-18 (vector times float)

@@ -1,0 +1,667 @@
+// rt_wavefront.h - the frame renderer as a wavefront of ray queues.
+//
+// The reference shades a camera sample by recursion (raytracing.cpp:61-274):
+// closest hit, one shadow query per light, then up to two child rays, five
+// levels deep.  Here every level of that recursion is one pass over a queue of
+// rays held in HBM:
+//
+//   k_wf_trace<false>   closest hit of every ray of the level   -> hit records
+//   k_wf_shade          hit geometry; emits the shadow rays (one queue per
+//                       light) and the child rays of the next level (compacted
+//                       with wave ballots + one atomic per wave); misses add
+//                       the background colour
+//   k_wf_trace<true>    any-hit query per shadow ray             -> occlusion flags
+//   k_wf_resolve        the light loop with the occlusion flags known; adds the
+//                       hit's weighted colour to its camera sample
+//
+// Queues are cut into regions.  Region r of every queue of a chunk belongs to
+// the same WF_REGION_SLOTS pixel slots: their camera rays, then whatever those
+// rays spawn, level after level.  A producer block owns one region, appends
+// into it densely with an LDS counter and publishes the fill count; no global
+// atomic is involved and a region cannot overflow (its size is the largest
+// number of rays its pixels can have in flight).  k_wf_worklist turns the fill
+// counts into a list of 64-ray work items; the two trace kernels are
+// persistent: a fixed grid of waves pulls items off that list with one atomic
+// per 256 rays until it is empty, so no launch depends on a count the host
+// would have to read back.  They keep the KD nodes and the traversal stack in
+// LDS and none of the shading state in registers, which is what gives them the
+// occupancy to hide the latency of the dependent node -> triangle loads.
+//
+// A camera sample's colour is the sum over its ray tree of (path weight x
+// local colour); the recursion is linear in the child colours
+// (raytracing.cpp:191, 240, 259, 268).  The sum is accumulated in 64-bit fixed
+// point (2^-32 units), so it does not depend on the order in which rays
+// finish: frames are bit-reproducible and independent of the tile partition.
+#pragma once
+#include "rt_device.h"
+
+#pragma clang fp contract(off)
+
+#define WF_BLOCK 256
+#define WF_MAX_DEPTH 6 // ray levels k = 0..5 (raytracing.cpp:63,166-168)
+#define WF_FIX_SCALE 4294967296.0
+
+__device__ __forceinline__ float wf_clamp01(float v) // RGBValue, imageWriter.h:26-44
+{
+    if (v > 1.0f) v = 1.0f;
+    if (v < 0.0f) v = 0.0f;
+    return v;
+}
+
+#define WF_REGION_SLOTS 512 // pixel slots per region
+#define WF_ITEMS_PER_FETCH 4 // 64-ray work items taken per atomic
+
+struct WfCounters {
+    int head_rays[WF_MAX_DEPTH + 1]; // persistent-kernel fetch counters, one per launch
+    int head_shadow[WF_MAX_DEPTH][RT_MAX_LIGHTS_DEV];
+    int pad[2];
+};
+
+// One queue of rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
+struct WfRays {
+    float4* o_w;  // origin xyz, path weight
+    float4* d_ni; // destination xyz, prev_Ni
+    uint2*  meta; // x: sample index, y: k | shared << 8
+    int*    cnt;  // [G] rays in each region
+};
+
+struct WfBuffers {
+    WfRays         rays[2];   // ping-pong between levels
+    float4*        hits;      // per ray slot: bits(orig triangle or -1), a, b, t
+    float*         wlocal;    // per ray slot: weight of the hit's own colour (0 for a miss)
+    float4*        sh_org;    // [light][cap]: shadow ray origin xyz, bits(ray slot)
+    int*           sh_cnt;    // [light][G]
+    unsigned char* occl;      // [light][cap]: 1 = occluded, indexed by ray slot
+    int*           prefix;    // [G + 1] for the ray queue, then [lights * G + 1] for the shadow queues
+    long long*     acc;       // [3][n_samples] fixed-point colour sums
+    float*         s_minT;    // per sample: t of the camera ray's hit (FLT_MAX = miss)
+    int*           s_tri;     // per sample: triangle of the camera ray's hit
+    WfCounters*    ctr;
+    int            cap;       // slots of every queue = G * R
+    int            G, R;      // regions, slots per region
+    int            n_samples; // samples of a chunk (upper bound)
+};
+
+// ---------------------------------------------------------------------------
+// work lists and the persistent trace kernels
+// ---------------------------------------------------------------------------
+// The first n_lds nodes (the top of the tree, nodes are stored top-down) are read from
+// the LDS copy, the rest from global memory.
+__device__ __forceinline__ DNode wf_node(const DScene& S, const DNode* lds_nodes, int n_lds, int i)
+{
+    if (i < n_lds) return lds_nodes[i];
+    return S.nodes[i];
+}
+
+// Work-item prefix sums: item counts ceil(cnt / 64) per region, exclusive scan.
+// Block 0: the G regions of ray queue `q`.  Block 1: the n_lights * G regions of the
+// shadow queues (light-major), one list for all lights.
+__global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int n_lights)
+{
+    __shared__ int s_part[1024];
+    const int      n = blockIdx.x == 0 ? B.G : n_lights * B.G;
+    const int*     cnt = blockIdx.x == 0 ? B.rays[q].cnt : B.sh_cnt;
+    int*           out = blockIdx.x == 0 ? B.prefix : B.prefix + (B.G + 1);
+    const int      per = (n + 1023) / 1024;
+    const int      lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+    int            sum = 0;
+    for (int i = lo; i < hi; ++i) sum += (cnt[i] + 63) >> 6;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // inclusive scan of the per-thread sums
+        int v = 0;
+        if ((int)threadIdx.x >= off) v = s_part[threadIdx.x - off];
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) {
+        out[i] = run;
+        run += (cnt[i] + 63) >> 6;
+    }
+    if (threadIdx.x == 1023) out[n] = s_part[1023];
+}
+
+// Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray.  Inner nodes carry
+// no triangles (they were handed down to the leaves).  A stack entry names the inner node
+// whose far child is still to be visited; the far child and its entry t are recomputed
+// from that node when it is popped (same expression as when it was pushed, hence the
+// same value).  The result equals the reference's leaf walk (raytracing.cpp:281-351): the
+// smallest t over all triangles, ties to the triangle that walk would have tested last.
+template <bool ANY>
+__device__ __forceinline__ bool wf_traverse(const DScene& S, const DNode* __restrict__ lds_nodes, int n_lds,
+                                            unsigned short* stk, f3 o, f3 d, HitRec& h,
+                                            unsigned& n_tests, unsigned& n_nodes)
+{
+    float minT = RT_FLT_MAX;
+    h.slot = -1, h.a = 0.0f, h.b = 0.0f;
+    int         best_orig = -1;
+    int         node = 0, sp = 0;
+    float       tmin = 0.0f, tmax = RT_FLT_MAX;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    for (;;) {
+        DNode nd = wf_node(S, lds_nodes, n_lds, node);
+        ++n_nodes;
+        while (nd.left >= 0) {
+            const int   axis = nd.cnt_axis >> 28;
+            const float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+            const float ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
+            const bool  below = (oa < nd.split) || (oa == nd.split && da <= 0.0f);
+            const float tplane = (nd.split - oa) * ia;
+            int         next;
+            if (da == 0.0f || tplane <= 0.0f || !(tplane <= tmax * (1.0f + RT_TRAV_EPS))) {
+                next = nd.left + (below ? 0 : 1);
+            } else if (tplane < tmin * (1.0f - RT_TRAV_EPS)) {
+                next = nd.left + (below ? 1 : 0);
+            } else {
+                stk[sp * WF_BLOCK] = (unsigned short)node;
+                ++sp;
+                next = nd.left + (below ? 0 : 1);
+                tmax = tplane;
+            }
+            node = next;
+            nd = wf_node(S, lds_nodes, n_lds, node);
+            ++n_nodes;
+        }
+        const int cnt = nd.cnt_axis & 0x0fffffff;
+        for (int i = 0; i < cnt; ++i) {
+            const int    slot = nd.tri_off + i;
+            const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
+            float        a, b, t;
+            ++n_tests;
+            if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
+                if (ANY) return true;
+                const int orig = __float_as_int(q2.w);
+                bool      take = t != minT || best_orig < 0;
+                if (!take) take = S.tri_rank[orig] > S.tri_rank[best_orig];
+                if (take) h.a = a, h.b = b, minT = t, best_orig = orig;
+            }
+        }
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            const int   p = stk[sp * WF_BLOCK];
+            const DNode pn = wf_node(S, lds_nodes, n_lds, p);
+            const int   axis = pn.cnt_axis >> 28;
+            const float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+            const float ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
+            const float et = (pn.split - oa) * ia;
+            if (!ANY && et > minT * (1.0f + RT_TRAV_EPS)) continue;
+            const bool below = (oa < pn.split) || (oa == pn.split && da <= 0.0f);
+            node = pn.left + (below ? 1 : 0);
+            tmin = et;
+            tmax = RT_FLT_MAX;
+            if (sp > 0) {
+                const DNode qn = wf_node(S, lds_nodes, n_lds, stk[(sp - 1) * WF_BLOCK]);
+                const int   qa = qn.cnt_axis >> 28;
+                const float qo = qa == 0 ? o.x : (qa == 1 ? o.y : o.z);
+                const float qi = qa == 0 ? ix : (qa == 1 ? iy : iz);
+                tmax = (qn.split - qo) * qi;
+            }
+            found = true;
+            break;
+        }
+        if (!found) break;
+    }
+    h.t = minT;
+    h.slot = best_orig; // the triangle, not the slot
+    return best_orig >= 0;
+}
+
+// Persistent trace kernel: a fixed grid of waves pulls 64-ray work items off the list
+// (WF_ITEMS_PER_FETCH per atomic) until it is empty.  The 64 lanes of a wave start
+// their rays together: neighbouring rays visit the same nodes and leaves at the same
+// time, so most of a wave's loads fall into a few cache lines.  (Refilling single lanes
+// as their rays finish was measured: it keeps more lanes busy but scatters the lanes
+// over the tree, and the extra cache lines per load cost more than the idle lanes.)
+//   ANY = false: queue of a level -> hit records.
+//   ANY = true : shadow queues of all lights of a level, one region list after the other
+//                (work list of n_lights * G regions); every ray of light li ends at
+//                lights[li] -> occlusion bytes.
+// LDS: [ top of the KD node array | per-thread stack of ushort node indices ].
+template <bool ANY>
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ d_ni, DParams const* lights,
+           const int* __restrict__ cnt, const int* __restrict__ prefix, int G, int n_regions, int R, int cap,
+           int* head, float4* hits, unsigned char* occl, DCounters* ctr, int n_lds)
+{
+    extern __shared__ __align__(16) unsigned char s_mem[];
+    DNode* nodes = (DNode*)s_mem;
+    for (int i = threadIdx.x; i < n_lds; i += WF_BLOCK) nodes[i] = S.nodes[i];
+    __syncthreads();
+    unsigned short* stk = (unsigned short*)(s_mem + (size_t)n_lds * sizeof(DNode)) + threadIdx.x;
+    const int       total = prefix[n_regions];
+    const int       lane = threadIdx.x & 63;
+    unsigned        n_tests = 0, n_nodes = 0, n_rays = 0;
+    int             r = 0; // region of the previous item: consecutive items mostly share it
+    for (;;) {
+        int t0 = 0;
+        if (lane == 0) t0 = atomicAdd(head, WF_ITEMS_PER_FETCH);
+        t0 = __builtin_amdgcn_readfirstlane(t0);
+        if (t0 >= total) break;
+        const int t1 = min(t0 + WF_ITEMS_PER_FETCH, total);
+        for (int t = t0; t < t1; ++t) {
+            if (!(prefix[r] <= t && t < prefix[r + 1])) { // wave-uniform binary search
+                int lo = 0, hi = n_regions; // invariant: prefix[lo] <= t < prefix[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (prefix[mid] <= t) lo = mid;
+                    else hi = mid;
+                }
+                r = lo;
+            }
+            const int idx = (t - prefix[r]) * 64 + lane;
+            if (idx >= cnt[r]) continue;
+            const int    li = ANY ? r / G : 0; // shadow regions are numbered light-major
+            const int    rr = r - li * G;
+            const size_t i = (size_t)li * cap + (size_t)rr * R + idx;
+            const float4 ow = o_w[i];
+            const f3     o = mk3(ow.x, ow.y, ow.z);
+            f3           dst;
+            if (ANY) dst = mk3(lights->lights[3 * li], lights->lights[3 * li + 1], lights->lights[3 * li + 2]);
+            else {
+                const float4 dn = d_ni[i];
+                dst = mk3(dn.x, dn.y, dn.z);
+            }
+            HitRec h;
+            ++n_rays;
+            const bool got = wf_traverse<ANY>(S, nodes, n_lds, stk, o, dst - o, h, n_tests, n_nodes);
+            if (ANY) occl[(size_t)li * cap + __float_as_int(ow.w)] = got ? 1 : 0;
+            else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        n_tests += __shfl_down(n_tests, s);
+        n_nodes += __shfl_down(n_nodes, s);
+        n_rays += __shfl_down(n_rays, s);
+    }
+    if (lane == 0) {
+        atomicAdd(&ctr->tri_tests, (unsigned long long)n_tests);
+        atomicAdd(&ctr->node_visits, (unsigned long long)n_nodes);
+        atomicAdd(ANY ? &ctr->rays_shadow : &ctr->rays_closest, (unsigned long long)n_rays);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// queue helpers
+// ---------------------------------------------------------------------------
+// Positions inside the block's own region: `per` consecutive slots for every
+// lane with mine == true; one LDS atomic per wave.
+__device__ __forceinline__ int wf_append(int* lds_counter, bool mine, int per = 1)
+{
+    const unsigned long long m = __ballot(mine);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int       base = 0;
+    if (lane == leader) base = atomicAdd(lds_counter, __popcll(m) * per);
+    base = __shfl(base, leader);
+    return mine ? base + __popcll(m & ((1ull << lane) - 1ull)) * per : -1;
+}
+
+__device__ __forceinline__ void wf_acc_add(const WfBuffers& B, unsigned sample, f3 c, bool shared)
+{
+    const long long r = (long long)llrint((double)c.x * WF_FIX_SCALE);
+    const long long g = (long long)llrint((double)c.y * WF_FIX_SCALE);
+    const long long b = (long long)llrint((double)c.z * WF_FIX_SCALE);
+    long long*      pr = B.acc + sample;
+    long long*      pg = B.acc + (size_t)B.n_samples + sample;
+    long long*      pb = B.acc + 2 * (size_t)B.n_samples + sample;
+    if (shared) { // several rays of this sample may be in the level: order-free integer adds
+        atomicAdd((unsigned long long*)pr, (unsigned long long)r);
+        atomicAdd((unsigned long long*)pg, (unsigned long long)g);
+        atomicAdd((unsigned long long*)pb, (unsigned long long)b);
+    } else { // the only ray of its sample in this level
+        *pr += r;
+        *pg += g;
+        *pb += b;
+    }
+}
+
+// Hit geometry shared by k_wf_shade and k_wf_resolve: raytracing.cpp:76-108.
+struct WfSurf {
+    f3    hp, N, viewDir, dir;
+    f3    Kd, Ks;
+    float Ns, Ni;
+    int   illum, has_Ni, tex;
+    int4  info;
+};
+
+__device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dst, float4 hit, WfSurf& s)
+{
+    const int orig = __float_as_int(hit.x);
+    s.dir = dst - o;
+    s.hp = o + s.dir * hit.w; // raytracing.cpp:384
+    const float4 s0 = S.tri_shade[3 * orig], s1 = S.tri_shade[3 * orig + 1], s2 = S.tri_shade[3 * orig + 2];
+    s.info = S.tri_info[orig];
+    const float4 m0 = S.mats[4 * s.info.x], m1 = S.mats[4 * s.info.x + 1], m2 = S.mats[4 * s.info.x + 2];
+    s.Kd = mk3(m0.x, m0.y, m0.z), s.Ks = mk3(m1.x, m1.y, m1.z);
+    s.Ns = m0.w, s.Ni = m1.w;
+    s.illum = __float_as_int(m2.x), s.has_Ni = __float_as_int(m2.y), s.tex = __float_as_int(m2.z);
+    const float u = hit.y, v = hit.z, w = 1.0f - u - v;
+    s.N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
+    normalize3(s.N);
+    s.viewDir = o - s.hp;
+    normalize3(s.viewDir);
+}
+
+// Per-light terms of raytracing.cpp:110-143 up to the shadow query: returns
+// whether a shadow ray is cast and the self-shadow value set before it.
+__device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lightDir, float& angle,
+                                               float& shadowMax)
+{
+    lightDir = lpos - s.hp;
+    normalize3(lightDir);
+    angle = dot3(lightDir, s.N);
+    if (angle <= 0.2f) shadowMax = 1.0f;
+    else if (angle < 0.5f) {
+        angle -= 0.2f;
+        shadowMax = 3.33f * (0.3f - angle);
+    }
+    return angle > 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// shade: one block per region, one thread per ray of level `level`
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_shade(DScene S, DParams P, WfBuffers B, int level)
+{
+    __shared__ int s_child;
+    __shared__ int s_sh[RT_MAX_LIGHTS_DEV];
+    const int      r = blockIdx.x;
+    const WfRays   in = B.rays[level & 1], out = B.rays[(level + 1) & 1];
+    const int      n = in.cnt[r];
+    const size_t   base = (size_t)r * B.R;
+    if (threadIdx.x == 0) s_child = 0;
+    if ((int)threadIdx.x < P.n_lights) s_sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int n_pad = (n + 63) & ~63; // whole waves iterate together: the ballots need every lane
+    for (int j = threadIdx.x; j < n_pad; j += WF_BLOCK) {
+        const bool   valid = j < n;
+        const size_t i = base + j;
+        uint2        meta = make_uint2(0, 0);
+        float4       ow = make_float4(0, 0, 0, 0), dn = make_float4(0, 0, 0, 0), hit = make_float4(0, 0, 0, 0);
+        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = B.hits[i];
+        const int   orig = valid ? __float_as_int(hit.x) : -1;
+        const int   k = (int)(meta.y & 0xff);
+        bool        shared = (meta.y >> 8) & 1;
+        const f3    o = mk3(ow.x, ow.y, ow.z), dst = mk3(dn.x, dn.y, dn.z);
+        const float w = ow.w;
+        if (valid && k == 0) { // the camera ray fixes the sample's depth and triangle
+            B.s_minT[meta.x] = hit.w;
+            B.s_tri[meta.x] = orig;
+        }
+        float      wl = 0.0f;
+        WfSurf     s;
+        const bool is_hit = valid && orig >= 0;
+        if (valid && !is_hit) // raytracing.cpp:74
+            wf_acc_add(B, meta.x, mk3(P.bg[0], P.bg[1], P.bg[2]) * w, shared);
+        if (is_hit) wf_surface(S, o, dst, hit, s);
+        // ---- shadow rays, one queue per light ----
+        float shadowMax = 0.0f;
+        for (int li = 0; li < P.n_lights; ++li) {
+            bool cast = false;
+            f3   lightDir = mk3(0, 0, 0);
+            if (is_hit) {
+                float angle;
+                cast = wf_light_setup(s, mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
+                                      lightDir, angle, shadowMax);
+            }
+            const int pos = wf_append(&s_sh[li], cast);
+            if (cast) {
+                const f3 so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
+                B.sh_org[(size_t)li * B.cap + base + pos] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+            }
+        }
+        // ---- children, raytracing.cpp:166-271 ----
+        int   nchild = 0;
+        f3    c_o[2], c_d[2];
+        float c_w[2];
+        float n2 = 1.0f;
+        if (is_hit) {
+            wl = w;
+            const int newK = k + 1;
+            if (newK < 5) {
+                const float n1 = (dn.w != 0.0f) ? dn.w : 1.0f;
+                n2 = s.has_Ni ? s.Ni : 1.0f;
+                if (s.illum == 3) {
+                    const f3 refl = s.dir - s.N * (2.0f * dot3(s.N, s.dir));
+                    wl = 0.5f * w;
+                    c_o[0] = s.hp + refl * 0.001f, c_d[0] = s.hp + refl, c_w[0] = 0.5f * w;
+                    nchild = 1;
+                } else if (s.Ni > 1.0f) {
+                    f3 I = s.dir;
+                    normalize3(I);
+                    const float eta = (n1 != n2) ? n2 : __fdiv_rn(1.0f, n2);
+                    const float cosI = dot3(I, s.N);
+                    const float sin2T =
+                        (float)(((double)eta * (double)eta) * (1.0 - ((double)cosI * (double)cosI)));
+                    float rf = sin2T;
+                    rf = rf < 0.0f ? 0.0f : rf;
+                    rf = rf > 1.0f ? 1.0f : rf;
+                    float wLocal = 0.5f * rf;
+                    if (sin2T <= 1.0f) {
+                        const float f = (float)((double)(eta * cosI) - sqrt((double)(1.0f - sin2T)));
+                        const f3    tRay = I * eta + s.N * f;
+                        wLocal += 0.1f * (1.0f - rf);
+                        const float wT = 0.9f * (1.0f - rf) * w;
+                        if (wT != 0.0f) {
+                            c_o[nchild] = s.hp + tRay * 0.001f, c_d[nchild] = s.hp + tRay, c_w[nchild] = wT;
+                            ++nchild;
+                        }
+                    }
+                    const float wR = 0.5f * rf * w;
+                    if (wR != 0.0f) {
+                        const f3 refRay = I - s.N * (2.0f * dot3(I, s.N));
+                        c_o[nchild] = s.hp + refRay * 0.001f, c_d[nchild] = s.hp + refRay, c_w[nchild] = wR;
+                        ++nchild;
+                    }
+                    wl = wLocal * w;
+                    shared = shared || nchild > 1;
+                }
+            }
+        }
+        if (valid) B.wlocal[i] = wl;
+        for (int c = 0; c < 2; ++c) {
+            const bool mine = c < nchild;
+            const int  pos = wf_append(&s_child, mine);
+            if (mine && pos < B.R) { // cannot exceed R by construction; the guard keeps a bug from writing outside
+                const size_t p = base + pos;
+                out.o_w[p] = make_float4(c_o[c].x, c_o[c].y, c_o[c].z, c_w[c]);
+                out.d_ni[p] = make_float4(c_d[c].x, c_d[c].y, c_d[c].z, n2);
+                out.meta[p] = make_uint2(meta.x, (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out.cnt[r] = min(s_child, B.R);
+    if ((int)threadIdx.x < P.n_lights) B.sh_cnt[(size_t)threadIdx.x * B.G + r] = s_sh[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// resolve: the light loop of raytracing.cpp:110-164 with the shadow queries answered
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
+{
+    const int    r = blockIdx.x;
+    const WfRays in = B.rays[level & 1];
+    const int    n = in.cnt[r];
+    const size_t base = (size_t)r * B.R;
+    const float  shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
+    for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
+        const size_t i = base + j;
+        const float  wl = B.wlocal[i];
+        const float4 hit = B.hits[i];
+        if (__float_as_int(hit.x) < 0) continue;
+        const uint2  meta = in.meta[i];
+        const float4 ow = in.o_w[i], dn = in.d_ni[i];
+        WfSurf       s;
+        wf_surface(S, mk3(ow.x, ow.y, ow.z), mk3(dn.x, dn.y, dn.z), hit, s);
+        f3 res;
+        if (s.tex < 0) res = s.Kd * P.backgroundlighting; // raytracing.cpp:92-95
+        else res = sample_texture(S, s.tex, s.info, s.hp);
+        float shadowMax = 0.0f; // carried from light to light (raytracing.cpp:104)
+        for (int li = 0; li < P.n_lights; ++li) {
+            const f3 lpos = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
+            f3       lightDir = lpos - s.hp;
+            normalize3(lightDir);
+            float angle = dot3(s.N, lightDir);
+            if (angle > 0.0f) res = res + (s.Kd * angle) * P.diffusePower;
+            angle = dot3(lightDir, s.N);
+            if (angle <= 0.2f) shadowMax = 1.0f;
+            else if (angle < 0.5f) {
+                angle -= 0.2f;
+                shadowMax = 3.33f * (0.3f - angle);
+            }
+            if (angle > 0.0f) {
+                f3 halfway = lightDir + s.viewDir;
+                normalize3(halfway);
+                angle = dot3(s.N, halfway);
+                if (angle > 0.0f) res = res + s.Ks * powf(angle, s.Ns);
+                if (B.occl[(size_t)li * B.cap + i]) shadowMax = 1.0f;
+            }
+            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow = 0)
+            const float sm = shadowMax * shadowPart;
+            res = res - mk3(sm, sm, sm);
+        }
+        wf_acc_add(B, meta.x, res * wl, (meta.y >> 8) & 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// camera rays
+// ---------------------------------------------------------------------------
+// Block r: centre rays of pixel slots slot0 + [r * S, (r + 1) * S) that lie inside
+// the frame, appended to region r of queue 0.  meta.x = slot - slot0.
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
+{
+    __shared__ int s_n;
+    const int      r = blockIdx.x;
+    const WfRays   q = B.rays[0];
+    const size_t   base = (size_t)r * B.R;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < WF_REGION_SLOTS; j += WF_BLOCK) {
+        const int i = r * WF_REGION_SLOTS + j;
+        int       x = 0, y = 0;
+        const bool valid = i < n && slot_to_pixel(P, slot0 + i, x, y);
+        const int  pos = wf_append(&s_n, valid);
+        if (valid) {
+            f3 o, d;
+            pixel_ray(P, (double)x, (double)y, o, d);
+            q.o_w[base + pos] = make_float4(o.x, o.y, o.z, 1.0f);
+            q.d_ni[base + pos] = make_float4(d.x, d.y, d.z, 1.0f); // prev_Ni = 1.0f (main.cpp:528)
+            q.meta[base + pos] = make_uint2((unsigned)i, 0u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q.cnt[r] = s_n;
+        atomicAdd(&ctr->camera_rays, (unsigned long long)s_n);
+    }
+}
+
+// MSAA > 1, after the centre rays are traced: misses are final pixels; every hit
+// pixel queues its `msaa` sample rays (main.cpp:445-507) into region r of queue 1.
+// Sample index = (slot - slot0) * msaa + s.
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth, int* tri,
+               unsigned char* centre_hit, DCounters* ctr)
+{
+    __shared__ int s_n;
+    const int      r = blockIdx.x;
+    const WfRays   in = B.rays[0], q = B.rays[1];
+    const int      n = in.cnt[r];
+    const size_t   base = (size_t)r * B.R;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int n_pad = (n + 63) & ~63;
+    for (int j = threadIdx.x; j < n_pad; j += WF_BLOCK) {
+        const bool valid = j < n;
+        bool       got = false;
+        int        x = 0, y = 0, slot = 0;
+        if (valid) {
+            slot = (int)in.meta[base + j].x;
+            const float4 hit = B.hits[base + j];
+            got = __float_as_int(hit.x) >= 0;
+            slot_to_pixel(P, slot0 + slot, x, y);
+            const size_t p = (size_t)y * P.W + x;
+            if (tri) tri[p] = __float_as_int(hit.x);
+            centre_hit[slot] = got ? 1 : 0;
+            if (!got) {
+                rgb[3 * p] = wf_clamp01(P.bg[0]);
+                rgb[3 * p + 1] = wf_clamp01(P.bg[1]);
+                rgb[3 * p + 2] = wf_clamp01(P.bg[2]);
+                depth[p] = RT_FLT_MAX;
+            }
+        }
+        const int pos = wf_append(&s_n, got, P.msaa);
+        if (got && pos + P.msaa <= B.R) {
+            for (int s = 0; s < P.msaa; ++s) {
+                const float ox = P.msaa == 4 ? c_msaa4[s][0] : c_msaa16[s][0];
+                const float oy = P.msaa == 4 ? c_msaa4[s][1] : c_msaa16[s][1];
+                f3          o, d;
+                pixel_ray(P, (double)x + (double)ox, (double)y + (double)oy, o, d);
+                const size_t p = base + pos + s;
+                q.o_w[p] = make_float4(o.x, o.y, o.z, 1.0f);
+                q.d_ni[p] = make_float4(d.x, d.y, d.z, 1.0f);
+                q.meta[p] = make_uint2((unsigned)(slot * P.msaa + s), 0u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q.cnt[r] = min(s_n, B.R);
+        atomicAdd(&ctr->camera_rays, (unsigned long long)s_n);
+    }
+}
+
+// Pixels from sample sums.  MSAA == 1: sample index = slot - slot0.  MSAA > 1:
+// ordered float sum of the samples / msaa, depth = mean of minT over the samples
+// that hit (main.cpp:449-507); only pixels whose centre ray hit.
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned char* __restrict__ centre_hit,
+              float* rgb, float* depth, int* tri)
+{
+    const int i = blockIdx.x * WF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int x, y;
+    if (!slot_to_pixel(P, slot0 + i, x, y)) return;
+    const size_t p = (size_t)y * P.W + x;
+    const size_t ns = (size_t)B.n_samples;
+    if (P.msaa == 1) {
+        const float r = (float)((double)B.acc[i] / WF_FIX_SCALE);
+        const float g = (float)((double)B.acc[ns + i] / WF_FIX_SCALE);
+        const float b = (float)((double)B.acc[2 * ns + i] / WF_FIX_SCALE);
+        rgb[3 * p] = wf_clamp01(r);
+        rgb[3 * p + 1] = wf_clamp01(g);
+        rgb[3 * p + 2] = wf_clamp01(b);
+        depth[p] = B.s_minT[i];
+        if (tri) tri[p] = B.s_tri[i];
+        return;
+    }
+    if (!centre_hit[i]) return;
+    float r = 0, g = 0, b = 0, dsum = 0;
+    int   hits = 0;
+    for (int s = 0; s < P.msaa; ++s) {
+        const size_t k = (size_t)i * P.msaa + s;
+        const float  sr = (float)((double)B.acc[k] / WF_FIX_SCALE);
+        const float  sg = (float)((double)B.acc[ns + k] / WF_FIX_SCALE);
+        const float  sb = (float)((double)B.acc[2 * ns + k] / WF_FIX_SCALE);
+        if (s == 0) r = sr, g = sg, b = sb;
+        else r += sr, g += sg, b += sb;
+        const float mt = B.s_minT[k];
+        if (mt != RT_FLT_MAX) dsum += mt, ++hits;
+    }
+    const float nn = (float)P.msaa;
+    rgb[3 * p] = wf_clamp01(__fdiv_rn(r, nn));
+    rgb[3 * p + 1] = wf_clamp01(__fdiv_rn(g, nn));
+    rgb[3 * p + 2] = wf_clamp01(__fdiv_rn(b, nn));
+    depth[p] = hits > 0 ? __fdiv_rn(dsum, (float)hits) : RT_FLT_MAX;
+}
