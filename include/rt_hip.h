@@ -127,8 +127,10 @@ typedef struct RtSceneInfo {
  * last collected, from HIP events recorded on the render stream around each
  * launch (no host synchronisation inside the render call). */
 typedef struct RtKernelTimes {
-    double  centre_ms, samples_ms, resolve_ms;
-    int32_t centre_launches, samples_launches, resolve_launches;
+    double  trace_closest_ms; /* closest-hit trace kernel launches */
+    double  trace_any_ms;     /* any-hit (shadow) trace kernel launches */
+    double  frame_ms;         /* first to last kernel of each render call */
+    int32_t trace_closest_launches, trace_any_launches, frames;
     int32_t reserved;
 } RtKernelTimes;
 

@@ -66,9 +66,9 @@ class RtStats(C.Structure):
 
 
 class RtKernelTimes(C.Structure):
-    _fields_ = [("centre_ms", C.c_double), ("samples_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("centre_launches", C.c_int32), ("samples_launches", C.c_int32),
-                ("resolve_launches", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("trace_closest_ms", C.c_double), ("trace_any_ms", C.c_double), ("frame_ms", C.c_double),
+                ("trace_closest_launches", C.c_int32), ("trace_any_launches", C.c_int32),
+                ("frames", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RtSceneInfo(C.Structure):

@@ -407,6 +407,9 @@ struct RtScene {
     int        wf_nodes_in_lds = 0;
     void*      wf_mem = nullptr;   // one allocation carved into the queues
     void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
+    hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t  wf_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t  wf_fork = nullptr;
     size_t     wf_mem_bytes = 0;
     // optional per-kernel timing (rt_scene_set_timing)
     bool                                 timing = false;
@@ -415,7 +418,7 @@ struct RtScene {
     size_t                               ev_used = 0;
 };
 
-enum { K_CENTRE = 0, K_SAMPLES = 1, K_RESOLVE = 2 };
+enum { K_TRACE_CLOSEST = 0, K_TRACE_ANY = 1, K_FRAME = 2 };
 #define RT_MAX_TIMED 4096
 
 // Event pair around one launch when timing is on; returns the pair index or -1.
@@ -465,6 +468,11 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 4; ++k) {
+        if (s->wf_stream[k]) (void)hipStreamDestroy(s->wf_stream[k]);
+        if (s->wf_join[k]) (void)hipEventDestroy(s->wf_join[k]);
+    }
+    if (s->wf_fork) (void)hipEventDestroy(s->wf_fork);
     delete s;
 }
 
@@ -873,9 +881,9 @@ extern "C" int rt_scene_collect_timing(RtScene* s, RtKernelTimes* out)
         float ms = 0;
         if (hipEventElapsedTime(&ms, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]) != hipSuccess) continue;
         switch (s->ev_kind[i]) {
-        case K_CENTRE: out->centre_ms += ms, out->centre_launches++; break;
-        case K_SAMPLES: out->samples_ms += ms, out->samples_launches++; break;
-        default: out->resolve_ms += ms, out->resolve_launches++; break;
+        case K_TRACE_CLOSEST: out->trace_closest_ms += ms, out->trace_closest_launches++; break;
+        case K_TRACE_ANY: out->trace_any_ms += ms, out->trace_any_launches++; break;
+        default: out->frame_ms += ms, out->frames++; break;
         }
     }
     s->ev_used = 0;
@@ -1094,7 +1102,7 @@ struct WfPlan {
     int       n_samples;   // samples per chunk
 };
 
-static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots)
+static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes)
 {
     // rays of one level per camera sample: 1 along mirror chains, up to 2^4 with refraction
     // (levels k = 0..4 spawn, raytracing.cpp:166-168)
@@ -1104,7 +1112,7 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots)
     const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8) + 16 + 4 + (size_t)L * 17) +
                               (size_t)WF_REGION_SLOTS * P.msaa * (3 * 8 + 4 + 4) + WF_REGION_SLOTS +
                               (size_t)(2 + 2 * (1 + L)) * 4;
-    long long g_max = (long long)(WF_WORKSPACE_BUDGET / per_region);
+    long long g_max = (long long)(WF_WORKSPACE_BUDGET / n_pipes / per_region);
     g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
     g_max = std::max<long long>(g_max, 1);
     const long long g_need = (n_slots + WF_REGION_SLOTS - 1) / WF_REGION_SLOTS;
@@ -1116,14 +1124,16 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots)
     return pl;
 }
 
-static int wf_carve(RtScene* s, const WfPlan& pl, int L, WfBuffers* B, unsigned char** centre_flags)
+#define WF_MAX_PIPES 4
+
+static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
 {
     const size_t cap = (size_t)pl.G * pl.R, ns = (size_t)pl.n_samples, G = (size_t)pl.G;
     size_t       need = 0;
-    size_t       off[24];
     int          k = 0;
     auto         take = [&](size_t bytes) {
-        off[k++] = need;
+        if (off) off[k] = need;
+        ++k;
         need += align256(bytes);
     };
     for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 8), take(G * 4); // 0..7
@@ -1138,13 +1148,13 @@ static int wf_carve(RtScene* s, const WfPlan& pl, int L, WfBuffers* B, unsigned 
     take(ns * 4);                              // 16 s_tri
     take(sizeof(WfCounters));                  // 17
     take((size_t)pl.chunk_slots);              // 18 centre flags
-    if (need > s->wf_mem_bytes) {
-        if (s->wf_mem) (void)hipFree(s->wf_mem);
-        s->wf_mem = nullptr, s->wf_mem_bytes = 0;
-        HIP_TRY(hipMalloc(&s->wf_mem, need));
-        s->wf_mem_bytes = need;
-    }
-    unsigned char* m = (unsigned char*)s->wf_mem;
+    return need;
+}
+
+// Buffers of pipeline `pipe` inside the scene's workspace.
+static void wf_carve(unsigned char* m, const WfPlan& pl, WfBuffers* B, unsigned char** centre_flags,
+                     const size_t* off)
+{
     for (int q = 0; q < 2; ++q) {
         B->rays[q].o_w = (float4*)(m + off[4 * q]);
         B->rays[q].d_ni = (float4*)(m + off[4 * q + 1]);
@@ -1162,74 +1172,133 @@ static int wf_carve(RtScene* s, const WfPlan& pl, int L, WfBuffers* B, unsigned 
     B->s_tri = (int*)(m + off[16]);
     B->ctr = (WfCounters*)(m + off[17]);
     *centre_flags = m + off[18];
-    B->cap = (int)cap;
+    B->cap = pl.G * pl.R;
     B->G = pl.G, B->R = pl.R;
     B->n_samples = pl.n_samples;
-    return RT_OK;
 }
 
 static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hipStream_t st)
 {
+    const int te = timing_begin(s, K_TRACE_CLOSEST, st);
     hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
                        (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
                        (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.hits,
                        (unsigned char*)nullptr, s->d_ctr, s->wf_nodes_in_lds);
+    timing_end(s, te, st);
 }
 
+// One frame part (the pixel slots [0, n_slots) of this rank).  The slots are cut into
+// chunks that fit the workspace.  RT_WF_PIPES > 1 puts that many chunks in flight on
+// streams of their own; measured on MI355X this is slower than one chunk after the
+// other (8 GPUs' share of a 4K frame: 7.8 ms with 1 pipeline, 8.6 / 9.9 / 12.5 ms with
+// 2 / 3 / 4), so the default is 1.
 static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, float* d_rgb, float* d_depth,
-                            int32_t* d_tri, hipStream_t st)
+                            int32_t* d_tri, hipStream_t user)
 {
     int rc = wf_prepare(s);
     if (rc) return rc;
-    const WfPlan   pl = wf_plan(s, P, n_slots);
-    const int      L = std::max(P.n_lights, 1);
-    WfBuffers      B;
-    unsigned char* centre_flags = nullptr;
-    if ((rc = wf_carve(s, pl, L, &B, &centre_flags))) return rc;
+    const int L = std::max(P.n_lights, 1);
+    // pipelines: enough chunks to overlap tails, but no chunk below ~64k pixel slots
+    const char* pipes_env = getenv("RT_WF_PIPES");
+    int         n_pipes = pipes_env ? atoi(pipes_env) : 1;
+    n_pipes = std::max(1, std::min(n_pipes, WF_MAX_PIPES));
+    n_pipes = (int)std::max<long long>(1, std::min<long long>(n_pipes, n_slots / 65536));
+    WfPlan pl = wf_plan(s, P, (n_slots + n_pipes - 1) / n_pipes, n_pipes);
+    size_t off[24];
+    const size_t per_pipe = wf_chunk_bytes(pl, L, off);
+    const size_t need = per_pipe * n_pipes;
+    if (need > s->wf_mem_bytes) {
+        if (s->wf_mem) (void)hipFree(s->wf_mem);
+        s->wf_mem = nullptr, s->wf_mem_bytes = 0;
+        HIP_TRY(hipMalloc(&s->wf_mem, need));
+        s->wf_mem_bytes = need;
+    }
     if (!s->d_params) HIP_TRY(hipMalloc(&s->d_params, sizeof(DParams)));
-    HIP_TRY(hipMemcpyAsync(s->d_params, &P, sizeof(DParams), hipMemcpyHostToDevice, st));
-    for (long long slot0 = 0; slot0 < n_slots; slot0 += pl.chunk_slots) {
-        const int n = (int)std::min<long long>(pl.chunk_slots, n_slots - slot0);
-        HIP_TRY(hipMemsetAsync(B.ctr, 0, sizeof(WfCounters), st));
-        HIP_TRY(hipMemsetAsync(B.acc, 0, (size_t)pl.n_samples * 8 * 3, st));
-        WfBuffers C = B;
-        hipLaunchKernelGGL(k_wf_gen_centre, dim3(C.G), dim3(WF_BLOCK), 0, st, P, C, slot0, n, s->d_ctr);
-        hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C, 0, 0);
-        int te = timing_begin(s, K_CENTRE, st);
-        wf_launch_trace(s, C, 0, &C.ctr->head_rays[WF_MAX_DEPTH], st);
-        timing_end(s, te, st);
+    for (int k = 0; k < n_pipes; ++k)
+        if (!s->wf_stream[k]) {
+            HIP_TRY(hipStreamCreateWithFlags(&s->wf_stream[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&s->wf_join[k], hipEventDisableTiming));
+        }
+    if (!s->wf_fork) HIP_TRY(hipEventCreateWithFlags(&s->wf_fork, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(s->d_params, &P, sizeof(DParams), hipMemcpyHostToDevice, user));
+    const int te = timing_begin(s, K_FRAME, user);
+    HIP_TRY(hipEventRecord(s->wf_fork, user));
+    WfBuffers      C[WF_MAX_PIPES];
+    unsigned char* flags[WF_MAX_PIPES];
+    for (int k = 0; k < n_pipes; ++k) {
+        HIP_TRY(hipStreamWaitEvent(s->wf_stream[k], s->wf_fork, 0));
+        wf_carve((unsigned char*)s->wf_mem + per_pipe * k, pl, &C[k], &flags[k], off);
+    }
+    for (long long round0 = 0; round0 < n_slots; round0 += pl.chunk_slots * n_pipes) {
+        long long slot0[WF_MAX_PIPES];
+        int       n[WF_MAX_PIPES];
+        int       live = 0;
+        for (int k = 0; k < n_pipes; ++k) {
+            slot0[k] = round0 + pl.chunk_slots * k;
+            n[k] = (int)std::max<long long>(0, std::min<long long>(pl.chunk_slots, n_slots - slot0[k]));
+            if (n[k] > 0) live = k + 1;
+        }
+        WfBuffers V[WF_MAX_PIPES]; // this round's view (ray queues get swapped for MSAA)
+        for (int k = 0; k < live; ++k) {
+            hipStream_t st = s->wf_stream[k];
+            V[k] = C[k];
+            HIP_TRY(hipMemsetAsync(V[k].ctr, 0, sizeof(WfCounters), st));
+            HIP_TRY(hipMemsetAsync(V[k].acc, 0, (size_t)pl.n_samples * 8 * 3, st));
+            hipLaunchKernelGGL(k_wf_gen_centre, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], n[k],
+                               s->d_ctr);
+            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0, 0);
+        }
+        for (int k = 0; k < live; ++k)
+            wf_launch_trace(s, V[k], 0, &V[k].ctr->head_rays[WF_MAX_DEPTH], s->wf_stream[k]);
         HIP_TRY(hipGetLastError());
         bool traced0 = true;
         if (P.msaa > 1) {
-            hipLaunchKernelGGL(k_wf_msaa_emit, dim3(C.G), dim3(WF_BLOCK), 0, st, P, C, slot0, d_rgb, d_depth,
-                               d_tri, centre_flags, s->d_ctr);
-            std::swap(C.rays[0], C.rays[1]);
-            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C, 0, 0);
+            for (int k = 0; k < live; ++k) {
+                hipStream_t st = s->wf_stream[k];
+                hipLaunchKernelGGL(k_wf_msaa_emit, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], d_rgb,
+                                   d_depth, d_tri, flags[k], s->d_ctr);
+                std::swap(V[k].rays[0], V[k].rays[1]);
+                hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0, 0);
+            }
             traced0 = false;
         }
-        te = timing_begin(s, K_SAMPLES, st);
         for (int level = 0; level < 5; ++level) {
             const int q = level & 1;
-            if (level > 0 || !traced0) wf_launch_trace(s, C, q, &C.ctr->head_rays[level], st);
-            hipLaunchKernelGGL(k_wf_shade, dim3(C.G), dim3(WF_BLOCK), 0, st, s->d, P, C, level);
-            // work lists of the next level's rays (block 0) and of this level's shadow queues
-            hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, C, q ^ 1,
-                               P.n_lights);
-            if (P.n_lights > 0)
-                hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st,
-                                   s->d, (const float4*)C.sh_org, (const float4*)nullptr,
-                                   (const DParams*)s->d_params, (const int*)C.sh_cnt,
-                                   (const int*)(C.prefix + (C.G + 1)), C.G, P.n_lights * C.G, C.R, C.cap,
-                                   &C.ctr->head_shadow[level][0], (float4*)nullptr, C.occl, s->d_ctr,
-                                   s->wf_nodes_in_lds);
-            hipLaunchKernelGGL(k_wf_resolve, dim3(C.G), dim3(WF_BLOCK), 0, st, s->d, P, C, level);
+            for (int k = 0; k < live; ++k) {
+                hipStream_t st = s->wf_stream[k];
+                if (level > 0 || !traced0) wf_launch_trace(s, V[k], q, &V[k].ctr->head_rays[level], st);
+                hipLaunchKernelGGL(k_wf_shade, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level);
+                // work lists of the next level's rays (block 0) and of this level's shadow queues
+                hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, V[k], q ^ 1,
+                                   P.n_lights);
+            }
+            for (int k = 0; k < live; ++k) {
+                hipStream_t st = s->wf_stream[k];
+                if (P.n_lights > 0) {
+                    const int ta = timing_begin(s, K_TRACE_ANY, st);
+                    hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st,
+                                       s->d, (const float4*)V[k].sh_org, (const float4*)nullptr,
+                                       (const DParams*)s->d_params, (const int*)V[k].sh_cnt,
+                                       (const int*)(V[k].prefix + (V[k].G + 1)), V[k].G, P.n_lights * V[k].G,
+                                       V[k].R, V[k].cap, &V[k].ctr->head_shadow[level][0], (float4*)nullptr,
+                                       V[k].occl, s->d_ctr, s->wf_nodes_in_lds);
+                    timing_end(s, ta, st);
+                }
+                hipLaunchKernelGGL(k_wf_resolve, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level);
+            }
             HIP_TRY(hipGetLastError());
         }
-        timing_end(s, te, st);
-        hipLaunchKernelGGL(k_wf_finalize, dim3(blocks_for(n, WF_BLOCK)), dim3(WF_BLOCK), 0, st, P, C, slot0, n,
-                           (const unsigned char*)centre_flags, d_rgb, d_depth, d_tri);
+        for (int k = 0; k < live; ++k)
+            hipLaunchKernelGGL(k_wf_finalize, dim3(blocks_for(n[k], WF_BLOCK)), dim3(WF_BLOCK), 0,
+                               s->wf_stream[k], P, V[k], slot0[k], n[k], (const unsigned char*)flags[k], d_rgb,
+                               d_depth, d_tri);
         HIP_TRY(hipGetLastError());
     }
+    for (int k = 0; k < n_pipes; ++k) {
+        HIP_TRY(hipEventRecord(s->wf_join[k], s->wf_stream[k]));
+        HIP_TRY(hipStreamWaitEvent(user, s->wf_join[k], 0));
+    }
+    timing_end(s, te, user);
     return RT_OK;
 }
 
@@ -1257,25 +1326,25 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
         if ((rc = ensure_workspace(s, n_slots, P.msaa))) return rc;
         const size_t lds = stack_bytes(s);
         if (P.msaa == 1) {
-            const int tc = timing_begin(s, K_CENTRE, stream);
+            const int tc = timing_begin(s, K_FRAME, stream);
             hipLaunchKernelGGL(k_centre<true>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
                                stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, (unsigned char*)nullptr,
                                s->d_ctr);
             timing_end(s, tc, stream);
             HIP_TRY(hipGetLastError());
         } else {
-            int te = timing_begin(s, K_CENTRE, stream);
+            int te = timing_begin(s, K_FRAME, stream);
             hipLaunchKernelGGL(k_centre<false>, dim3(blocks_for(n_slots, RT_BLOCK)), dim3(RT_BLOCK), lds,
                                stream, s->d, P, n_slots, d_rgb, d_depth, d_tri, s->d_flags, s->d_ctr);
             timing_end(s, te, stream);
             HIP_TRY(hipGetLastError());
-            te = timing_begin(s, K_SAMPLES, stream);
+            te = timing_begin(s, K_FRAME, stream);
             hipLaunchKernelGGL(k_samples, dim3(blocks_for(n_slots * P.msaa, RT_BLOCK)), dim3(RT_BLOCK),
                                lds, stream, s->d, P, n_slots, (const unsigned char*)s->d_flags,
                                s->d_samples, s->d_ctr);
             timing_end(s, te, stream);
             HIP_TRY(hipGetLastError());
-            te = timing_begin(s, K_RESOLVE, stream);
+            te = timing_begin(s, K_FRAME, stream);
             hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_slots, 256)), dim3(256), 0, stream, P,
                                n_slots, (const unsigned char*)s->d_flags,
                                (const float4*)s->d_samples, d_rgb, d_depth);

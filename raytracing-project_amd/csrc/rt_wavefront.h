@@ -237,12 +237,15 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
     const int       lane = threadIdx.x & 63;
     unsigned        n_tests = 0, n_nodes = 0, n_rays = 0;
     int             r = 0; // region of the previous item: consecutive items mostly share it
+    // several items per atomic while there is plenty of work, single items when the
+    // list is short compared with the waves in flight (keeps the tail of the launch short)
+    const int per_fetch = total >= 8 * (int)gridDim.x * (WF_BLOCK / 64) ? WF_ITEMS_PER_FETCH : 1;
     for (;;) {
         int t0 = 0;
-        if (lane == 0) t0 = atomicAdd(head, WF_ITEMS_PER_FETCH);
+        if (lane == 0) t0 = atomicAdd(head, per_fetch);
         t0 = __builtin_amdgcn_readfirstlane(t0);
         if (t0 >= total) break;
-        const int t1 = min(t0 + WF_ITEMS_PER_FETCH, total);
+        const int t1 = min(t0 + per_fetch, total);
         for (int t = t0; t < t1; ++t) {
             if (!(prefix[r] <= t && t < prefix[r + 1])) { // wave-uniform binary search
                 int lo = 0, hi = n_regions; // invariant: prefix[lo] <= t < prefix[hi]

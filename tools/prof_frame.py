@@ -11,6 +11,9 @@ gs = hs.to_gpu(0)
 m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
 corners = host.camera_corners(m, W, H)
 p = capi.default_params(W, H, msaa)
+import os as _os
+if _os.environ.get('WORLD'):
+    p.tile_w = p.tile_h = 32; p.world = int(_os.environ['WORLD']); p.rank = int(_os.environ.get('RANK', '0'))
 for _ in range(frames):
     rgb, depth, tri, st = gs.render(corners, lights, p)
 rays = st.rays_closest + st.rays_shadow
