@@ -390,6 +390,7 @@ struct RtScene {
     void*   d_texinfo = nullptr;
     void*   d_texels = nullptr;
     void*   d_rank = nullptr;
+    void*   d_knodes = nullptr;
     int     tree_depth = 0;
     size_t  bytes = 0;
     // per-call workspace, grown on demand
@@ -404,7 +405,6 @@ struct RtScene {
     bool       refractive = false; // some material can spawn two child rays
     int        wf_grid_trace = 0, wf_grid_any = 0;
     size_t     wf_lds = 0;
-    int        wf_nodes_in_lds = 0;
     void*      wf_mem = nullptr;   // one allocation carved into the queues
     void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
     hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -462,7 +462,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -657,8 +657,10 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         // RT_KD_REFINE=0 switches it off.
         const char* rf_env = getenv("RT_KD_REFINE");
         if (!(rf_env && rf_env[0] == '0')) {
-            const int    leaf_target = 4;       // do not split leaves at or below this size
-            const double c_trav = 1.0, c_isect = 3.0;
+            const char*  lt_env = getenv("RT_KD_LEAF");
+            const char*  ci_env = getenv("RT_KD_CI");
+            const int    leaf_target = lt_env ? atoi(lt_env) : 4; // do not split leaves at or below this size
+            const double c_trav = 1.0, c_isect = ci_env ? atof(ci_env) : 3.0;
             const size_t max_nodes = 60000;     // node indices are 16-bit on the traversal stack
             Box          mesh_box;
             for (int a = 0; a < 3; ++a) {
@@ -771,6 +773,17 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     }
     if (slots.size() / 3 >= (1u << 30))
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many triangle references");
+    std::vector<uint2> knodes(nodes.size());
+    for (size_t k = 0; k < nodes.size(); ++k) {
+        const DNode& n = nodes[k];
+        if (n.left >= 0) {
+            unsigned bits;
+            memcpy(&bits, &n.split, 4);
+            knodes[k] = make_uint2(bits, ((unsigned)(n.cnt_axis >> 28) << 30) | (unsigned)n.left);
+        } else {
+            knodes[k] = make_uint2((unsigned)n.tri_off, (3u << 30) | (unsigned)(n.cnt_axis & 0x0fffffff));
+        }
+    }
 
     std::vector<float4> shade((size_t)nt * 3);
     std::vector<int4>   info((size_t)nt);
@@ -821,7 +834,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
         (rc = upload(&s->d_texcoords, texcoords, &s->bytes)) ||
         (rc = upload(&s->d_mats, mats, &s->bytes)) || (rc = upload(&s->d_texinfo, texinfo, &s->bytes)) ||
-        (rc = upload(&s->d_texels, texels, &s->bytes)) || (rc = upload(&s->d_rank, rank, &s->bytes))) {
+        (rc = upload(&s->d_texels, texels, &s->bytes)) || (rc = upload(&s->d_rank, rank, &s->bytes)) || (rc = upload(&s->d_knodes, knodes, &s->bytes))) {
         rt_scene_destroy(s);
         return rc;
     }
@@ -841,6 +854,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.tex_info = (const int4*)s->d_texinfo;
     s->d.texels = (const uint8_t*)s->d_texels;
     s->d.tri_rank = (const int32_t*)s->d_rank;
+    s->d.knodes = (const uint2*)s->d_knodes;
     s->d.n_nodes = (int)nodes.size();
     s->d.n_slots = (int)(slots.size() / 3);
     s->d.n_triangles = nt;
@@ -1077,15 +1091,7 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int wf_prepare(RtScene* s)
 {
     if (s->wf_grid_trace) return RT_OK;
-    // LDS per block: the top of the node array + the traversal stacks, kept near 40 KB so
-    // that four blocks fit a CU
-    const size_t stack_bytes_ = (size_t)s->d.stack_entries * WF_BLOCK * sizeof(unsigned short);
-    const char*  lds_env = getenv("RT_WF_LDS_KB");
-    const size_t budget = (size_t)(lds_env ? atoi(lds_env) : 40) * 1024;
-    size_t       n_lds = stack_bytes_ < budget ? (budget - stack_bytes_) / sizeof(DNode) : 0;
-    n_lds = std::min<size_t>(n_lds, (size_t)s->d.n_nodes);
-    s->wf_nodes_in_lds = (int)n_lds;
-    s->wf_lds = n_lds * sizeof(DNode) + stack_bytes_;
+    s->wf_lds = (size_t)s->d.stack_entries * WF_BLOCK * sizeof(unsigned short);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
@@ -1183,7 +1189,7 @@ static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hi
     hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
                        (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
                        (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.hits,
-                       (unsigned char*)nullptr, s->d_ctr, s->wf_nodes_in_lds);
+                       (unsigned char*)nullptr, s->d_ctr);
     timing_end(s, te, st);
 }
 
@@ -1281,7 +1287,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                                        (const DParams*)s->d_params, (const int*)V[k].sh_cnt,
                                        (const int*)(V[k].prefix + (V[k].G + 1)), V[k].G, P.n_lights * V[k].G,
                                        V[k].R, V[k].cap, &V[k].ctr->head_shadow[level][0], (float4*)nullptr,
-                                       V[k].occl, s->d_ctr, s->wf_nodes_in_lds);
+                                       V[k].occl, s->d_ctr);
                     timing_end(s, ta, st);
                 }
                 hipLaunchKernelGGL(k_wf_resolve, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level);

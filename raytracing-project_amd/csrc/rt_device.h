@@ -37,8 +37,13 @@ struct DNode {
 //   q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
 //   q1 = e2.y e2.z v2.x v2.y
 //   q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
+// Compact form of the same tree for the wavefront trace kernels, 8 bytes per node:
+//   inner: x = bits(split plane), y = axis << 30 | index of the left child
+//   leaf : x = first triangle slot, y = 3 << 30 | triangle count
+// (only built when inner nodes carry no triangles of their own).
 struct DScene {
     const DNode*   nodes;
+    const uint2*   knodes;
     const float4*  tris;
     const float4*  tri_shade; // per original triangle: 3 float4 = nA nB nC (xyz) + w: material, t0|t1.., see pack
     const int4*    tri_info;  // per original triangle: material, t0, t1, t2
@@ -87,6 +92,36 @@ __device__ __forceinline__ float normalize3(f3& a)
     return len;
 }
 
+// a = na / D, b = nb / D, c = nc / D, each correctly rounded (round to nearest even), i.e.
+// bit-identical to IEEE division.  The instruction sequence is the one the compiler emits
+// for an f32 division (reciprocal, one Newton step, two residual corrections) with the
+// scaling and fix-up stages left out; those only act when an exponent is extreme, so the
+// short form is used when |D| and the numerators lie in [2^-40, 2^40] (or are zero) and the
+// full division otherwise.  The reciprocal refinement is shared by the three quotients.
+__device__ __forceinline__ void div3_rn(float na, float nb, float nc, float D, float& a, float& b, float& c)
+{
+    const float lo = 9.094947e-13f, hi = 1.0995116e12f; // 2^-40, 2^40
+    const float aD = fabsf(D), m1 = fabsf(na), m2 = fabsf(nb), m3 = fabsf(nc);
+    const bool  ok = aD >= lo && aD <= hi && (m1 == 0.0f || (m1 >= lo && m1 <= hi)) &&
+                    (m2 == 0.0f || (m2 >= lo && m2 <= hi)) && (m3 == 0.0f || (m3 >= lo && m3 <= hi));
+    if (ok) {
+        const float r0 = __builtin_amdgcn_rcpf(D);
+        const float e0 = __builtin_fmaf(-D, r0, 1.0f);
+        const float r1 = __builtin_fmaf(e0, r0, r0);
+        float q, e;
+        q = na * r1, e = __builtin_fmaf(-D, q, na), q = __builtin_fmaf(e, r1, q);
+        e = __builtin_fmaf(-D, q, na), a = __builtin_fmaf(e, r1, q);
+        q = nb * r1, e = __builtin_fmaf(-D, q, nb), q = __builtin_fmaf(e, r1, q);
+        e = __builtin_fmaf(-D, q, nb), b = __builtin_fmaf(e, r1, q);
+        q = nc * r1, e = __builtin_fmaf(-D, q, nc), q = __builtin_fmaf(e, r1, q);
+        e = __builtin_fmaf(-D, q, nc), c = __builtin_fmaf(e, r1, q);
+    } else {
+        a = __fdiv_rn(na, D);
+        b = __fdiv_rn(nb, D);
+        c = __fdiv_rn(nc, D);
+    }
+}
+
 struct HitRec {
     int   slot; // -1: miss
     float a, b, t;
@@ -115,9 +150,9 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
                          (cz * d.y) * e1x - dz_e1y * cx;
         const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
                          (cz * e1y) * e2x;
-        a = __fdiv_rn(da, D);
-        b = __fdiv_rn(db, D);
-        t = -__fdiv_rn(dt, D);
+        float q;
+        div3_rn(da, db, dt, D, a, b, q);
+        t = -q;
     }
     return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
 }

@@ -85,14 +85,6 @@ struct WfBuffers {
 // ---------------------------------------------------------------------------
 // work lists and the persistent trace kernels
 // ---------------------------------------------------------------------------
-// The first n_lds nodes (the top of the tree, nodes are stored top-down) are read from
-// the LDS copy, the rest from global memory.
-__device__ __forceinline__ DNode wf_node(const DScene& S, const DNode* lds_nodes, int n_lds, int i)
-{
-    if (i < n_lds) return lds_nodes[i];
-    return S.nodes[i];
-}
-
 // Work-item prefix sums: item counts ceil(cnt / 64) per region, exclusive scan.
 // Block 0: the G regions of ray queue `q`.  Block 1: the n_lights * G regions of the
 // shadow queues (light-major), one list for all lights.
@@ -123,54 +115,80 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int n_
     if (threadIdx.x == 1023) out[n] = s_part[1023];
 }
 
-// Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray.  Inner nodes carry
-// no triangles (they were handed down to the leaves).  A stack entry names the inner node
-// whose far child is still to be visited; the far child and its entry t are recomputed
-// from that node when it is popped (same expression as when it was pushed, hence the
-// same value).  The result equals the reference's leaf walk (raytracing.cpp:281-351): the
-// smallest t over all triangles, ties to the triangle that walk would have tested last.
+// Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray over the compact node
+// array.  Inner nodes carry no triangles (they were handed down to the leaves).  A stack
+// entry names the inner node whose far child is still to be visited; the far child and
+// its entry t are recomputed from that node when it is popped (same expression as when it
+// was pushed, hence the same value).  The traversal arithmetic (plane distances) is free
+// to use fused multiply-add: it only decides which cells are visited, with a safety
+// margin; which triangle is hit, and where, is decided by tri_test alone.  The result
+// equals the reference's leaf walk (raytracing.cpp:281-351): the smallest t over all
+// triangles, ties to the triangle that walk would have tested last.
 template <bool ANY>
-__device__ __forceinline__ bool wf_traverse(const DScene& S, const DNode* __restrict__ lds_nodes, int n_lds,
-                                            unsigned short* stk, f3 o, f3 d, HitRec& h,
+__device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
 {
     float minT = RT_FLT_MAX;
     h.slot = -1, h.a = 0.0f, h.b = 0.0f;
-    int         best_orig = -1;
-    int         node = 0, sp = 0;
-    float       tmin = 0.0f, tmax = RT_FLT_MAX;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    int   best_orig = -1;
+    int   node = 0, sp = 0;
+    float tmin_e = 0.0f, tmax_e = RT_FLT_MAX; // entry / exit t of the current cell, margins applied
+    // per axis: 1/d, o/d and whether d > 0.  A zero component gets a huge positive stand-in:
+    // the plane is then "reached" only at +-infinity-like t with the correct side.
+    const float big = 1e18f;
+    const float ix = d.x != 0.0f ? __builtin_amdgcn_rcpf(d.x) : big,
+                iy = d.y != 0.0f ? __builtin_amdgcn_rcpf(d.y) : big,
+                iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    const unsigned dpos = (ix > 0.0f ? 1u : 0u) | (iy > 0.0f ? 2u : 0u) | (iz > 0.0f ? 4u : 0u);
     for (;;) {
-        DNode nd = wf_node(S, lds_nodes, n_lds, node);
+        uint2 nd = S.knodes[node];
         ++n_nodes;
-        while (nd.left >= 0) {
-            const int   axis = nd.cnt_axis >> 28;
-            const float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
-            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-            const float ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
-            const bool  below = (oa < nd.split) || (oa == nd.split && da <= 0.0f);
-            const float tplane = (nd.split - oa) * ia;
-            int         next;
-            if (da == 0.0f || tplane <= 0.0f || !(tplane <= tmax * (1.0f + RT_TRAV_EPS))) {
-                next = nd.left + (below ? 0 : 1);
-            } else if (tplane < tmin * (1.0f - RT_TRAV_EPS)) {
-                next = nd.left + (below ? 1 : 0);
+        while ((nd.y >> 30) != 3u) {
+            const unsigned axis = nd.y >> 30;
+            const int      left = (int)(nd.y & 0x3fffffffu);
+            const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
+            const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
+            const float    tplane = __builtin_fmaf(__uint_as_float(nd.x), ia, -oi);
+            // origin side of the plane: below it iff (split - o) > 0 iff tplane and d agree in sign
+            const bool below = (tplane > 0.0f) == (((dpos >> axis) & 1u) != 0u);
+            const int  near = left + (below ? 0 : 1);
+            if (tplane <= 0.0f || !(tplane <= tmax_e)) {
+                node = near;
+            } else if (tplane < tmin_e) {
+                node = left + (below ? 1 : 0);
             } else {
                 stk[sp * WF_BLOCK] = (unsigned short)node;
                 ++sp;
-                next = nd.left + (below ? 0 : 1);
-                tmax = tplane;
+                node = near;
+                tmax_e = tplane * (1.0f + RT_TRAV_EPS);
             }
-            node = next;
-            nd = wf_node(S, lds_nodes, n_lds, node);
+            nd = S.knodes[node];
             ++n_nodes;
         }
-        const int cnt = nd.cnt_axis & 0x0fffffff;
+        const int cnt = (int)(nd.y & 0x3fffffffu);
+        const int first = (int)nd.x;
         for (int i = 0; i < cnt; ++i) {
-            const int    slot = nd.tri_off + i;
+            const int    slot = first + i;
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
             float        a, b, t;
             ++n_tests;
+#if defined(WF_ABLATE_DOUBLE_TEST) // timing experiment: the arithmetic of the test a second time
+            {
+                float a2, b2, t2;
+                f3    o2 = o;
+                asm volatile("" : "+v"(o2.x));
+                const bool r2 = tri_test(q0, q1, q2, o2, d, minT, a2, b2, t2);
+                asm volatile("" ::"v"(a2), "v"(b2), "v"(t2), "s"((int)r2));
+            }
+#endif
+#if defined(WF_ABLATE_DOUBLE_LOAD) // timing experiment: the triangle loads a second time
+            {
+                const int    s2 = first + ((i + 1) % cnt);
+                const float4 r0 = S.tris[3 * s2], r1 = S.tris[3 * s2 + 1], r2 = S.tris[3 * s2 + 2];
+                asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x), "v"(r0.w), "v"(r1.w), "v"(r2.w));
+            }
+#endif
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
@@ -182,24 +200,22 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const DNode* __rest
         bool found = false;
         while (sp > 0) {
             --sp;
-            const int   p = stk[sp * WF_BLOCK];
-            const DNode pn = wf_node(S, lds_nodes, n_lds, p);
-            const int   axis = pn.cnt_axis >> 28;
-            const float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
-            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-            const float ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
-            const float et = (pn.split - oa) * ia;
-            if (!ANY && et > minT * (1.0f + RT_TRAV_EPS)) continue;
-            const bool below = (oa < pn.split) || (oa == pn.split && da <= 0.0f);
-            node = pn.left + (below ? 1 : 0);
-            tmin = et;
-            tmax = RT_FLT_MAX;
+            const uint2    pn = S.knodes[stk[sp * WF_BLOCK]];
+            const unsigned axis = pn.y >> 30;
+            const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
+            const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
+            const float    et = __builtin_fmaf(__uint_as_float(pn.x), ia, -oi);
+            if (!ANY && et * (1.0f - RT_TRAV_EPS) > minT) continue;
+            const bool below = (et > 0.0f) == (((dpos >> axis) & 1u) != 0u);
+            node = (int)(pn.y & 0x3fffffffu) + (below ? 1 : 0);
+            tmin_e = et * (1.0f - RT_TRAV_EPS);
+            tmax_e = RT_FLT_MAX;
             if (sp > 0) {
-                const DNode qn = wf_node(S, lds_nodes, n_lds, stk[(sp - 1) * WF_BLOCK]);
-                const int   qa = qn.cnt_axis >> 28;
-                const float qo = qa == 0 ? o.x : (qa == 1 ? o.y : o.z);
-                const float qi = qa == 0 ? ix : (qa == 1 ? iy : iz);
-                tmax = (qn.split - qo) * qi;
+                const uint2    qn = S.knodes[stk[(sp - 1) * WF_BLOCK]];
+                const unsigned qa = qn.y >> 30;
+                const float    qi = qa == 0 ? ix : (qa == 1 ? iy : iz);
+                const float    qo = qa == 0 ? oix : (qa == 1 ? oiy : oiz);
+                tmax_e = __builtin_fmaf(__uint_as_float(qn.x), qi, -qo) * (1.0f + RT_TRAV_EPS);
             }
             found = true;
             break;
@@ -221,18 +237,17 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const DNode* __rest
 //   ANY = true : shadow queues of all lights of a level, one region list after the other
 //                (work list of n_lights * G regions); every ray of light li ends at
 //                lights[li] -> occlusion bytes.
-// LDS: [ top of the KD node array | per-thread stack of ushort node indices ].
+// LDS: per-thread stacks of ushort node indices.  (Keeping the top of the node array in
+// LDS too was measured: 27.7 ms per 4K frame without it, 29.9 / 32.5 / 39.5 ms with 32 / 48 /
+// 64 KB per block - the nodes stay in the vector L1 and the LDS costs occupancy.)
 template <bool ANY>
 __global__ void __launch_bounds__(WF_BLOCK)
 k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ d_ni, DParams const* lights,
            const int* __restrict__ cnt, const int* __restrict__ prefix, int G, int n_regions, int R, int cap,
-           int* head, float4* hits, unsigned char* occl, DCounters* ctr, int n_lds)
+           int* head, float4* hits, unsigned char* occl, DCounters* ctr)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
-    DNode* nodes = (DNode*)s_mem;
-    for (int i = threadIdx.x; i < n_lds; i += WF_BLOCK) nodes[i] = S.nodes[i];
-    __syncthreads();
-    unsigned short* stk = (unsigned short*)(s_mem + (size_t)n_lds * sizeof(DNode)) + threadIdx.x;
+    unsigned short* stk = (unsigned short*)s_mem + threadIdx.x;
     const int       total = prefix[n_regions];
     const int       lane = threadIdx.x & 63;
     unsigned        n_tests = 0, n_nodes = 0, n_rays = 0;
@@ -271,7 +286,7 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
             }
             HitRec h;
             ++n_rays;
-            const bool got = wf_traverse<ANY>(S, nodes, n_lds, stk, o, dst - o, h, n_tests, n_nodes);
+            const bool got = wf_traverse<ANY>(S, stk, o, dst - o, h, n_tests, n_nodes);
             if (ANY) occl[(size_t)li * cap + __float_as_int(ow.w)] = got ? 1 : 0;
             else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
         }
