@@ -13,11 +13,11 @@ stays in HBM.  Rank 0 prints one JSON line.
 
 value = rays traced by all ranks per second (closest-hit + shadow queries the
 GPUs executed).  roofline.achieved = algorithmic FLOP of the dominant kernel
-(k_wf_trace, the persistent KD traversal + ray/triangle kernel) divided by its
-duration from HIP events recorded inside the timed loop; the FLOP count is the
-traversal part 45 T + 40 S of F = 45 T + 40 S + 30 H + 60 Hl + 25 C, with the
-counters of the reference's algorithm (tests/golden/frame_counters.json,
-produced by tools/make_counters.py on the CPU oracle).
+(k_wf_pipeline, the persistent launch that renders a rank's part of the frame)
+divided by its duration from HIP events recorded inside the timed loop; the FLOP
+count is F = 45 T + 40 S + 30 H + 60 Hl + 25 C with the counters of the
+reference's algorithm (tests/golden/frame_counters.json, produced by
+tools/make_counters.py on the CPU oracle).
 """
 import argparse
 import importlib
@@ -182,49 +182,45 @@ def main():
                        "tri_tests_per_ray": round(tests_per_frame / rays_per_frame, 2),
                        "nodes_per_ray": round(nodes_per_frame / rays_per_frame, 2)},
         }
-        # roofline of the dominant kernel: k_wf_trace (closest-hit + any-hit launches).  Its
-        # algorithmic work is the traversal part of F: 45 flop per ray/triangle test and 40 per
-        # leaf step of the REFERENCE's walk of this frame (counted by the CPU oracle, fixture
-        # tests/golden/frame_counters.json); the duration is the sum of the HIP-event intervals
-        # around every trace launch of a frame on rank 0, averaged over the timed steps.
+        # roofline of the dominant kernel: k_wf_pipeline, the single persistent launch that renders
+        # this rank's part of the frame (camera rays, KD traversal + ray/triangle tests, shading,
+        # pixel resolve).  Its algorithmic work is F = 45 T + 40 S + 30 H + 60 Hl + 25 C with the
+        # counters of the REFERENCE's own algorithm for this frame (counted by the CPU oracle,
+        # fixture tests/golden/frame_counters.json); its duration comes from HIP events recorded
+        # on the launch stream around every launch inside the timed loop (rank 0).
         fc_path = os.path.join(ROOT, "tests", "golden", "frame_counters.json")
         key = f"{SCENE}_{W}x{H}_msaa{MSAA}"
         roof = None
-        n_tr = kt.trace_closest_launches + kt.trace_any_launches
-        if os.path.exists(fc_path) and n_tr > 0:
+        if os.path.exists(fc_path) and kt.frames > 0:
             fc = json.load(open(fc_path)).get(key)
             if fc:
-                f_trace = (45 * fc["frame"]["tri_tests"] + 40 * fc["frame"]["leaf_steps"]) / world
-                trace_ms = (kt.trace_closest_ms + kt.trace_any_ms) / args.steps
-                frame_ms = kt.frame_ms / max(kt.frames, 1)
-                ach = f_trace / (trace_ms * 1e-3) / 1e12
+                f_kernel = fc["flops_frame"] / world
+                kern_ms = kt.frame_ms / kt.frames
+                ach = f_kernel / (kern_ms * 1e-3) / 1e12
                 traffic = None
                 tp = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tp):
-                    traffic = json.load(open(tp)).get("k_wf_trace_hbm_bytes_per_frame")
+                    traffic = json.load(open(tp)).get("k_wf_pipeline_hbm_bytes_per_launch")
                 hbm_bytes = W * H * 16 + W * H * 16 + (W - 12) * (H - 12) * 12
-                roof = {"bound": "valu", "kernel": "k_wf_trace (all closest-hit and any-hit launches of a frame)",
-                        "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
-                        "kernel_ms_per_frame": round(trace_ms, 3),
-                        "launches_per_frame": round(n_tr / args.steps, 1),
-                        "avg_launch_ms": round((kt.trace_closest_ms + kt.trace_any_ms) / n_tr, 4),
-                        "algorithmic_gflop_per_frame": round(f_trace / 1e9, 2),
+                roof = {"bound": "valu", "kernel": "k_wf_pipeline", "achieved": round(ach, 3),
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
+                        "traffic": traffic, "kernel_ms": round(kern_ms, 3),
+                        "launches_per_frame": round(kt.frames / args.steps, 2),
+                        "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "note": "no MFMA on this path: the bound is the FP32 vector peak (= the f32 MFMA "
-                                "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk",
-                        "frame": {"algorithmic_gflop": round(fc["flops_frame"] / 1e9, 2),
-                                  "render_ms": round(frame_ms, 3),
-                                  "achieved_tflops": round(fc["flops_frame"] / world / (frame_ms * 1e-3) / 1e12, 3),
-                                  "frac": round(fc["flops_frame"] / world / (frame_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk "
+                                "(T = %d ray/triangle tests, S = %d leaf steps per frame)"
+                                % (fc["frame"]["tri_tests"], fc["frame"]["leaf_steps"]),
+                        "frame": {"ms_incl_dof_and_gather": round(ms, 3),
+                                  "achieved_tflops": round(fc["flops_frame"] / (ms * 1e-3) / 1e12, 3),
+                                  "frac": round(fc["flops_frame"] / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS / world, 4),
                                   "reference_rays": fc["frame"]["rays_closest"] + fc["frame"]["rays_shadow"]},
                         "hbm": {"algorithmic_bytes_per_frame": hbm_bytes,
                                 "achieved_gbs": round(hbm_bytes / (ms * 1e-3) / 1e9, 2),
                                 "peak_gbs": HBM_PEAK_GBS,
                                 "frac": round(hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         out["roofline"] = roof
-        out["kernel_ms"] = {"k_wf_trace_closest_per_frame": round(kt.trace_closest_ms / args.steps, 3),
-                            "k_wf_trace_any_per_frame": round(kt.trace_any_ms / args.steps, 3),
-                            "render_frame": round(kt.frame_ms / max(kt.frames, 1), 3),
+        out["kernel_ms"] = {"k_wf_pipeline": round(kt.frame_ms / max(kt.frames, 1), 3),
                             "dof_and_gather": round(ms - kt.frame_ms / max(kt.frames, 1), 3)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)

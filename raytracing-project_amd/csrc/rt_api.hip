@@ -403,7 +403,7 @@ struct RtScene {
     // wavefront renderer
     bool       pushdown = false;   // inner nodes carry no triangles
     bool       refractive = false; // some material can spawn two child rays
-    int        wf_grid_trace = 0, wf_grid_any = 0;
+    int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
     void*      wf_mem = nullptr;   // one allocation carved into the queues
     void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
@@ -1099,33 +1099,37 @@ static int wf_prepare(RtScene* s)
     s->wf_grid_trace = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<true>, WF_BLOCK, s->wf_lds));
     s->wf_grid_any = std::max(1, per_cu) * prop.multiProcessorCount;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline, WF_BLOCK, s->wf_lds));
+    s->wf_grid_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
     return RT_OK;
 }
 
 struct WfPlan {
-    long long chunk_slots; // pixel slots per chunk (a multiple of WF_REGION_SLOTS)
+    long long chunk_slots; // pixel slots per chunk (a multiple of S)
+    int       S;           // pixel slots per region
     int       G, R;        // regions per chunk, ray slots per region
     int       n_samples;   // samples per chunk
 };
 
-static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes)
+static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes, int S)
 {
     // rays of one level per camera sample: 1 along mirror chains, up to 2^4 with refraction
     // (levels k = 0..4 spawn, raytracing.cpp:166-168)
     const int       growth = s->refractive ? 16 : 1;
     const int       L = std::max(P.n_lights, 1);
-    const long long R = (long long)WF_REGION_SLOTS * P.msaa * growth;
+    const long long R = (long long)S * P.msaa * growth;
     const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8) + 16 + 4 + (size_t)L * 17) +
-                              (size_t)WF_REGION_SLOTS * P.msaa * (3 * 8 + 4 + 4) + WF_REGION_SLOTS +
+                              (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
                               (size_t)(2 + 2 * (1 + L)) * 4;
     long long g_max = (long long)(WF_WORKSPACE_BUDGET / n_pipes / per_region);
     g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
     g_max = std::max<long long>(g_max, 1);
-    const long long g_need = (n_slots + WF_REGION_SLOTS - 1) / WF_REGION_SLOTS;
+    const long long g_need = (n_slots + S - 1) / S;
     WfPlan          pl;
     pl.G = (int)std::min(g_need, g_max);
     pl.R = (int)R;
-    pl.chunk_slots = (long long)pl.G * WF_REGION_SLOTS;
+    pl.S = S;
+    pl.chunk_slots = (long long)pl.G * S;
     pl.n_samples = (int)(pl.chunk_slots * P.msaa);
     return pl;
 }
@@ -1179,7 +1183,7 @@ static void wf_carve(unsigned char* m, const WfPlan& pl, WfBuffers* B, unsigned 
     B->ctr = (WfCounters*)(m + off[17]);
     *centre_flags = m + off[18];
     B->cap = pl.G * pl.R;
-    B->G = pl.G, B->R = pl.R;
+    B->G = pl.G, B->R = pl.R, B->S = pl.S;
     B->n_samples = pl.n_samples;
 }
 
@@ -1209,7 +1213,20 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     int         n_pipes = pipes_env ? atoi(pipes_env) : 1;
     n_pipes = std::max(1, std::min(n_pipes, WF_MAX_PIPES));
     n_pipes = (int)std::max<long long>(1, std::min<long long>(n_pipes, n_slots / 65536));
-    WfPlan pl = wf_plan(s, P, (n_slots + n_pipes - 1) / n_pipes, n_pipes);
+    // pixel slots per region: small regions balance the blocks of the single-launch pipeline
+    // (a region is a block's unit of work), the multi-launch path is indifferent
+    const char* ml_env = getenv("RT_WF_MULTILAUNCH");
+    const bool  single = !(ml_env && ml_env[0] == '1');
+    const char* rg_env = getenv("RT_WF_REGION");
+    int         S = 512;
+    if (single) { // about 16 regions per resident block: 256 slots for a whole 4K frame, 64 for an eighth
+        const long long per_block = n_slots / (16LL * std::max(s->wf_grid_pipe, 1));
+        S = per_block >= 256 ? 256 : (per_block >= 128 ? 128 : 64);
+    }
+    if (rg_env) S = atoi(rg_env);
+    S = std::max(64, std::min(4096, (S / 64) * 64));
+    if (single) n_pipes = 1;
+    WfPlan pl = wf_plan(s, P, (n_slots + n_pipes - 1) / n_pipes, n_pipes, S);
     size_t off[24];
     const size_t per_pipe = wf_chunk_bytes(pl, L, off);
     const size_t need = per_pipe * n_pipes;
@@ -1243,6 +1260,14 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             slot0[k] = round0 + pl.chunk_slots * k;
             n[k] = (int)std::max<long long>(0, std::min<long long>(pl.chunk_slots, n_slots - slot0[k]));
             if (n[k] > 0) live = k + 1;
+        }
+        if (single) {
+            hipStream_t st = s->wf_stream[0];
+            HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
+            hipLaunchKernelGGL(k_wf_pipeline, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d, P, C[0],
+                               slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
+            HIP_TRY(hipGetLastError());
+            continue;
         }
         WfBuffers V[WF_MAX_PIPES]; // this round's view (ray queues get swapped for MSAA)
         for (int k = 0; k < live; ++k) {

@@ -15,7 +15,7 @@
 //                       hit's weighted colour to its camera sample
 //
 // Queues are cut into regions.  Region r of every queue of a chunk belongs to
-// the same WF_REGION_SLOTS pixel slots: their camera rays, then whatever those
+// the same S (128 to 512) pixel slots: their camera rays, then whatever those
 // rays spawn, level after level.  A producer block owns one region, appends
 // into it densely with an LDS counter and publishes the fill count; no global
 // atomic is involved and a region cannot overflow (its size is the largest
@@ -48,13 +48,21 @@ __device__ __forceinline__ float wf_clamp01(float v) // RGBValue, imageWriter.h:
     return v;
 }
 
-#define WF_REGION_SLOTS 512 // pixel slots per region
 #define WF_ITEMS_PER_FETCH 4 // 64-ray work items taken per atomic
 
 struct WfCounters {
     int head_rays[WF_MAX_DEPTH + 1]; // persistent-kernel fetch counters, one per launch
     int head_shadow[WF_MAX_DEPTH][RT_MAX_LIGHTS_DEV];
-    int pad[2];
+    int head_region;                 // k_wf_pipeline: next region to hand out
+    int pad;
+};
+
+// Block-local state of the producer stages (LDS).
+struct WfShared {
+    int child;                  // rays appended to the next level's region
+    int n;                      // rays appended by the camera stages
+    int region;                 // k_wf_pipeline: the region the block works on
+    int sh[RT_MAX_LIGHTS_DEV];  // shadow rays appended per light
 };
 
 // One queue of rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
@@ -78,7 +86,8 @@ struct WfBuffers {
     int*           s_tri;     // per sample: triangle of the camera ray's hit
     WfCounters*    ctr;
     int            cap;       // slots of every queue = G * R
-    int            G, R;      // regions, slots per region
+    int            G, R;      // regions, ray slots per region
+    int            S;         // pixel slots per region
     int            n_samples; // samples of a chunk (upper bound)
 };
 
@@ -385,15 +394,13 @@ __device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lig
 // ---------------------------------------------------------------------------
 // shade: one block per region, one thread per ray of level `level`
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_shade(DScene S, DParams P, WfBuffers B, int level)
+__device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& P, const WfBuffers& B,
+                                                const WfRays in, const WfRays out, int r, WfShared* sh)
 {
-    __shared__ int s_child;
-    __shared__ int s_sh[RT_MAX_LIGHTS_DEV];
-    const int      r = blockIdx.x;
-    const WfRays   in = B.rays[level & 1], out = B.rays[(level + 1) & 1];
-    const int      n = in.cnt[r];
-    const size_t   base = (size_t)r * B.R;
+    int&         s_child = sh->child;
+    int*         s_sh = sh->sh;
+    const int    n = in.cnt[r];
+    const size_t base = (size_t)r * B.R;
     if (threadIdx.x == 0) s_child = 0;
     if ((int)threadIdx.x < P.n_lights) s_sh[threadIdx.x] = 0;
     __syncthreads();
@@ -500,14 +507,19 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level)
     if ((int)threadIdx.x < P.n_lights) B.sh_cnt[(size_t)threadIdx.x * B.G + r] = s_sh[threadIdx.x];
 }
 
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_shade(DScene S, DParams P, WfBuffers B, int level)
+{
+    __shared__ WfShared sh;
+    wf_shade_region(S, P, B, B.rays[level & 1], B.rays[(level + 1) & 1], blockIdx.x, &sh);
+}
+
 // ---------------------------------------------------------------------------
 // resolve: the light loop of raytracing.cpp:110-164 with the shadow queries answered
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
+__device__ __forceinline__ void wf_resolve_region(const DScene& S, const DParams& P, const WfBuffers& B,
+                                                  const WfRays in, int r)
 {
-    const int    r = blockIdx.x;
-    const WfRays in = B.rays[level & 1];
     const int    n = in.cnt[r];
     const size_t base = (size_t)r * B.R;
     const float  shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
@@ -551,22 +563,27 @@ k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
     }
 }
 
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
+{
+    wf_resolve_region(S, P, B, B.rays[level & 1], blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------
 // camera rays
 // ---------------------------------------------------------------------------
 // Block r: centre rays of pixel slots slot0 + [r * S, (r + 1) * S) that lie inside
 // the frame, appended to region r of queue 0.  meta.x = slot - slot0.
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
+__device__ __forceinline__ void wf_gen_region(const DParams& P, const WfBuffers& B, const WfRays q,
+                                              long long slot0, int n, DCounters* ctr, int r, WfShared* sh)
 {
-    __shared__ int s_n;
-    const int      r = blockIdx.x;
-    const WfRays   q = B.rays[0];
-    const size_t   base = (size_t)r * B.R;
+    int&         s_n = sh->n;
+    const size_t base = (size_t)r * B.R;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < WF_REGION_SLOTS; j += WF_BLOCK) {
-        const int i = r * WF_REGION_SLOTS + j;
+    const int s_pad = (B.S + 63) & ~63;
+    for (int j = threadIdx.x; j < s_pad; j += WF_BLOCK) {
+        const int i = j < B.S ? r * B.S + j : n;
         int       x = 0, y = 0;
         const bool valid = i < n && slot_to_pixel(P, slot0 + i, x, y);
         const int  pos = wf_append(&s_n, valid);
@@ -585,18 +602,24 @@ k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
     }
 }
 
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
+{
+    __shared__ WfShared sh;
+    wf_gen_region(P, B, B.rays[0], slot0, n, ctr, blockIdx.x, &sh);
+}
+
 // MSAA > 1, after the centre rays are traced: misses are final pixels; every hit
 // pixel queues its `msaa` sample rays (main.cpp:445-507) into region r of queue 1.
 // Sample index = (slot - slot0) * msaa + s.
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth, int* tri,
-               unsigned char* centre_hit, DCounters* ctr)
+__device__ __forceinline__ void wf_msaa_region(const DParams& P, const WfBuffers& B, const WfRays in,
+                                               const WfRays q, long long slot0, float* rgb, float* depth,
+                                               int* tri, unsigned char* centre_hit, DCounters* ctr, int r,
+                                               WfShared* sh)
 {
-    __shared__ int s_n;
-    const int      r = blockIdx.x;
-    const WfRays   in = B.rays[0], q = B.rays[1];
-    const int      n = in.cnt[r];
-    const size_t   base = (size_t)r * B.R;
+    int&         s_n = sh->n;
+    const int    n = in.cnt[r];
+    const size_t base = (size_t)r * B.R;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int n_pad = (n + 63) & ~63;
@@ -640,15 +663,21 @@ k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth
     }
 }
 
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth, int* tri,
+               unsigned char* centre_hit, DCounters* ctr)
+{
+    __shared__ WfShared sh;
+    wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, blockIdx.x, &sh);
+}
+
 // Pixels from sample sums.  MSAA == 1: sample index = slot - slot0.  MSAA > 1:
 // ordered float sum of the samples / msaa, depth = mean of minT over the samples
 // that hit (main.cpp:449-507); only pixels whose centre ray hit.
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned char* __restrict__ centre_hit,
-              float* rgb, float* depth, int* tri)
+__device__ __forceinline__ void wf_finalize_slot(const DParams& P, const WfBuffers& B, long long slot0, int i,
+                                                 const unsigned char* __restrict__ centre_hit, float* rgb,
+                                                 float* depth, int* tri)
 {
-    const int i = blockIdx.x * WF_BLOCK + threadIdx.x;
-    if (i >= n) return;
     int x, y;
     if (!slot_to_pixel(P, slot0 + i, x, y)) return;
     const size_t p = (size_t)y * P.W + x;
@@ -682,4 +711,120 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
     rgb[3 * p + 1] = wf_clamp01(__fdiv_rn(g, nn));
     rgb[3 * p + 2] = wf_clamp01(__fdiv_rn(b, nn));
     depth[p] = hits > 0 ? __fdiv_rn(dsum, (float)hits) : RT_FLT_MAX;
+}
+
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned char* __restrict__ centre_hit,
+              float* rgb, float* depth, int* tri)
+{
+    const int i = blockIdx.x * WF_BLOCK + threadIdx.x;
+    if (i < n) wf_finalize_slot(P, B, slot0, i, centre_hit, rgb, depth, tri);
+}
+
+// ---------------------------------------------------------------------------
+// the whole frame part in one persistent launch
+// ---------------------------------------------------------------------------
+// A block takes a region (one atomic), runs every stage of its pixels - camera rays,
+// MSAA gating, five levels of trace / shade / shadow trace / resolve, pixel resolve - and
+// takes the next region.  Stages of a region are separated by block barriers only; there
+// is no device-wide synchronisation and no launch boundary inside the frame, so a CU
+// always has other blocks' stages to run while one block waits for its slowest ray, and
+// the bandwidth-bound stages of some blocks overlap the arithmetic-bound traces of others.
+template <bool ANY>
+__device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* __restrict__ o_w,
+                                                const float4* __restrict__ d_ni, f3 light, int n,
+                                                size_t base, float4* hits, unsigned char* occl,
+                                                unsigned short* stk, unsigned& n_tests, unsigned& n_nodes,
+                                                unsigned& n_rays)
+{
+    for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
+        const size_t i = base + j;
+        const float4 ow = o_w[i];
+        const f3     o = mk3(ow.x, ow.y, ow.z);
+        f3           dst = light;
+        if (!ANY) {
+            const float4 dn = d_ni[i];
+            dst = mk3(dn.x, dn.y, dn.z);
+        }
+        HitRec h;
+        ++n_rays;
+        const bool got = wf_traverse<ANY>(S, stk, o, dst - o, h, n_tests, n_nodes);
+        if (ANY) occl[__float_as_int(ow.w)] = got ? 1 : 0;
+        else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
+    }
+}
+
+// Compiled for 7 waves per SIMD (72 VGPRs; what does not fit spills, outside the traversal
+// loops).  Measured per 4K frame: 25.6 / 23.6 / 23.3 / 22.6 / 25.4 ms for 4 / 5 / 6 / 7 / 8.
+#ifndef WF_PIPE_WAVES
+#define WF_PIPE_WAVES 7
+#endif
+__global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
+k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* rgb, float* depth, int* tri,
+              unsigned char* centre_hit, DCounters* ctr)
+{
+    extern __shared__ __align__(16) unsigned char s_mem[];
+    __shared__ WfShared sh;
+    unsigned short*     stk = (unsigned short*)s_mem + threadIdx.x;
+    unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0;
+    const size_t        ns = (size_t)B.n_samples;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.region = atomicAdd(&B.ctr->head_region, 1);
+        __syncthreads();
+        const int r = sh.region;
+        if (r >= B.G) break;
+        const size_t base = (size_t)r * B.R;
+        for (int j = threadIdx.x; j < B.S * P.msaa; j += WF_BLOCK) { // this region's colour sums
+            const size_t k = (size_t)r * B.S * P.msaa + j;
+            B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
+        }
+        wf_gen_region(P, B, B.rays[0], slot0, n, ctr, r, &sh);
+        __syncthreads();
+        wf_trace_region<false>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base, B.hits,
+                               nullptr, stk, n_tests, n_nodes, n_closest);
+        __syncthreads();
+        int q0 = 0;
+        if (P.msaa > 1) {
+            wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, r, &sh);
+            __syncthreads();
+            q0 = 1;
+        }
+        for (int level = 0; level < 5; ++level) {
+            const WfRays in = B.rays[(q0 + level) & 1], out = B.rays[(q0 + level + 1) & 1];
+            const int    n_in = in.cnt[r];
+            if (n_in == 0) break;
+            if (level > 0 || q0 == 1) {
+                wf_trace_region<false>(S, in.o_w, in.d_ni, mk3(0, 0, 0), n_in, base, B.hits, nullptr, stk,
+                                       n_tests, n_nodes, n_closest);
+                __syncthreads();
+            }
+            wf_shade_region(S, P, B, in, out, r, &sh);
+            __syncthreads();
+            for (int li = 0; li < P.n_lights; ++li)
+                wf_trace_region<true>(S, B.sh_org + (size_t)li * B.cap, nullptr,
+                                      mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
+                                      B.sh_cnt[(size_t)li * B.G + r], base, nullptr,
+                                      B.occl + (size_t)li * B.cap, stk, n_tests, n_nodes, n_shadow);
+            __syncthreads();
+            wf_resolve_region(S, P, B, in, r);
+            __syncthreads();
+        }
+        for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
+            const int i = r * B.S + j;
+            if (i < n) wf_finalize_slot(P, B, slot0, i, centre_hit, rgb, depth, tri);
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        n_tests += __shfl_down(n_tests, s);
+        n_nodes += __shfl_down(n_nodes, s);
+        n_closest += __shfl_down(n_closest, s);
+        n_shadow += __shfl_down(n_shadow, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr->tri_tests, (unsigned long long)n_tests);
+        atomicAdd(&ctr->node_visits, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->rays_closest, (unsigned long long)n_closest);
+        atomicAdd(&ctr->rays_shadow, (unsigned long long)n_shadow);
+    }
 }

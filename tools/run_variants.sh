@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "4 3" "2 3" "2 5" "1 5" "1 8" "3 4"; do set -- $cfg
-  echo "== leaf=$1 ci=$2"; RT_KD_LEAF=$1 RT_KD_CI=$2 timeout -k 10 60 python3 tools/prof_frame.py final 3840 2160 4 3 2>&1 | grep -v materials | tail -1 || exit 1
+for w in 7 8; do
+  echo "== pipe waves=$w"; RT_HIP_LIB=$GRAFT_REPO_ROOT/raytracing-project_amd/csrc/variants/librt_hip_p$w.so timeout -k 10 60 python3 tools/prof_frame.py final 3840 2160 4 3 2>&1 | grep -v materials | tail -1 || exit 1
+  RT_HIP_LIB=$GRAFT_REPO_ROOT/raytracing-project_amd/csrc/variants/librt_hip_p$w.so WORLD=8 RT_WF_REGION=64 timeout -k 10 60 python3 tools/prof_frame.py final 3840 2160 4 3 2>&1 | grep -v materials | tail -1 || exit 1
 done
