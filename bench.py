@@ -202,7 +202,9 @@ def main():
                 if os.path.exists(tp):
                     traffic = json.load(open(tp)).get("k_wf_pipeline_hbm_bytes_per_launch")
                 hbm_bytes = W * H * 16 + W * H * 16 + (W - 12) * (H - 12) * 12
-                roof = {"bound": "valu", "kernel": "k_wf_pipeline", "achieved": round(ach, 3),
+                roof = {"bound": "mfma", "bound_detail": "fp32 vector ALU; the path has no matrix-shaped work, "
+                        "so the ceiling is the FP32 rate, which is the same 157.3 TFLOP/s for vector FMA "
+                        "and dense f32 MFMA", "kernel": "k_wf_pipeline", "achieved": round(ach, 3),
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                         "traffic": traffic, "kernel_ms": round(kern_ms, 3),
                         "launches_per_frame": round(kt.frames / args.steps, 2),

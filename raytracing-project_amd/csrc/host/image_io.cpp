@@ -48,7 +48,7 @@ bool writeColour(const char* filename, const float* img, int w, int h, unsigned 
 {
     FILE* f = fopen(filename, "wb");
     if (!f) {
-        printf("dump file problem... file\n");
+        fprintf(stderr, "dump file problem... file\n");
         return false;
     }
     putHeaders(f, sizeField, w, h);
@@ -65,7 +65,7 @@ bool writeColour(const char* filename, const float* img, int w, int h, unsigned 
         for (int i = 3 * w; i < rs; ++i) row[i - padShift] = 1; // imageWriter.h:326-328 / 456-458
     }
     const bool ok = fwrite(bytes.data(), (size_t)w * h * 3, 1, f) == 1;
-    if (!ok) printf("Dump file problem... fwrite\n");
+    if (!ok) fprintf(stderr, "Dump file problem... fwrite\n");
     fclose(f);
     return ok;
 }
@@ -76,7 +76,7 @@ bool Image::writeImagePPM(const char* filename) const
 {
     FILE* f = fopen(filename, "wb");
     if (!f) {
-        printf("dump file problem... file\n");
+        fprintf(stderr, "dump file problem... file\n");
         return false;
     }
     fprintf(f, "P6\n%i %i\n255\n", width, height);
@@ -103,7 +103,7 @@ bool Image::writeDepthBMP(const char* filename) const
 {
     FILE* f = fopen(filename, "wb");
     if (!f) {
-        printf("dump file problem... file\n");
+        fprintf(stderr, "dump file problem... file\n");
         return false;
     }
     putHeaders(f, (unsigned)(3 * width * height), width, height);

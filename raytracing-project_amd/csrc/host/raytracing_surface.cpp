@@ -137,7 +137,7 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir)
         return -1.0;
     }
     const int W = result.width, H = result.height;
-    printf("\nRaytracing a complete %i x %i image \n", W, H);
+    fprintf(stderr, "\nRaytracing a complete %i x %i image \n", W, H);
     RtParams p = MySettings;
     p.width = W, p.height = H;
     p.focusDepth = focusDepth;
@@ -150,7 +150,7 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir)
         return -1.0;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("\nRaytracing comlete in %g seconds, storing result...\n", secs);
+    fprintf(stderr, "\nRaytracing comlete in %g seconds, storing result...\n", secs);
     const std::string dir = std::string(out_dir && *out_dir ? out_dir : ".") + "/";
     bool              ok = result.writeImagePPM((dir + "result.ppm").c_str());
     ok = result.writeImageBMP((dir + "result.bmp").c_str()) && ok;
@@ -179,7 +179,7 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir)
         g_error = "could not write the result files into " + dir;
         return -1.0;
     }
-    printf("Stored result in result.ppm, result.bmp, depth.bmp and blurred.bmp\n");
+    fprintf(stderr, "Stored result in result.ppm, result.bmp, depth.bmp and blurred.bmp\n");
     return secs;
 }
 

@@ -13,6 +13,8 @@
 // RGBA8, zlib-compressed; see tools/decode_textures.py); '\' in a map_Kd path
 // becomes '/', relative paths resolve against the .obj directory and absolute
 // paths are not found, as on any machine but the scene authors'.
+// Progress and warning lines the reference prints go to stderr here: stdout is left to
+// the embedding program (bench.py prints one JSON line there).
 #include <zlib.h>
 
 #include <cctype>
@@ -64,7 +66,7 @@ void readMtl(const std::string& file, std::vector<PendingMaterial>& out,
 {
     FILE* in = fopen(file.c_str(), "r");
     if (!in) {
-        printf("  Warning! Material file '%s' not found!\n", file.c_str());
+        fprintf(stderr, "  Warning! Material file '%s' not found!\n", file.c_str());
         return;
     }
     MtlState    cur;
@@ -129,7 +131,7 @@ void readMtl(const std::string& file, std::vector<PendingMaterial>& out,
         if (feof(in) && indef && cur.valid() && !key.empty()) commit();
     }
     fclose(in);
-    printf("%u  materials loaded.\n", (unsigned)out.size() + 1);
+    fprintf(stderr, "%u  materials loaded.\n", (unsigned)out.size() + 1);
 }
 
 bool readRtex(const std::string& path, Texture& t)
@@ -234,7 +236,7 @@ bool Mesh::loadMesh(const char* filename, bool /*randomizeTriangulation*/, bool 
                 tri_texcoord.insert(tri_texcoord.end(), {ti[0], ti[i + 1], ti[i + 2]});
                 tri_material.push_back(current);
             }
-            if (vi.size() < 3) printf("TriMesh::LOAD: Unexpected number of face vertices (<3). Ignoring face");
+            if (vi.size() < 3) fprintf(stderr, "TriMesh::LOAD: Unexpected number of face vertices (<3). Ignoring face");
         }
     }
     fclose(in);
@@ -259,7 +261,7 @@ bool Mesh::loadMesh(const char* filename, bool /*randomizeTriangulation*/, bool 
                         textures.push_back(std::move(t));
                         found = (int)textures.size() - 1;
                     } else {
-                        printf("failed to read texture: %s\n", pm.texture.c_str());
+                        fprintf(stderr, "failed to read texture: %s\n", pm.texture.c_str());
                     }
                 }
                 pm.m.texture = found;

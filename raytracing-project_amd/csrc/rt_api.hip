@@ -291,9 +291,11 @@ __global__ void k_depth_normalize(float* depth, long long n, const float* __rest
 
 // ---- depth-of-field blur, imageWriter.h:137-231 ----
 // The 13x13 kernel of a pixel depends on (i-6)^2 + (j-6)^2 only through
-// -((..)/2) with integer division, i.e. 37 possible exponents; each thread
-// evaluates those powf once (table in LDS), then walks the 169 taps in the
-// reference's order for both the normalisation sum and the gather.
+// -((..)/2) with integer division, i.e. 37 possible exponents.  Each thread
+// evaluates those 37 powf once into an LDS table, walks the 169 taps in the
+// reference's order to form the normalisation sum (the float sum depends on
+// the order), divides the 37 table entries by it (the same operands as the 169
+// divisions of the reference, hence the same weights) and gathers.
 #define DOF_BLOCK 128
 __global__ void __launch_bounds__(DOF_BLOCK)
 k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int W, int H,
@@ -301,13 +303,15 @@ k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int 
 {
     __shared__ float s_tab[37 * DOF_BLOCK];
     const int        bw = W - 12, bh = H - 12;
-    const long long  idx = (long long)blockIdx.x * DOF_BLOCK + threadIdx.x;
-    if (idx >= (long long)bw * bh) return;
-    const int ox = (int)(idx % bw), oy = (int)(idx / bw);
+    // 16 x 8 pixel blocks: neighbouring threads share most of their taps' cache lines
+    const int tiles_x = (bw + 15) >> 4;
+    const int ox = (blockIdx.x % tiles_x) * 16 + (threadIdx.x & 15);
+    const int oy = (blockIdx.x / tiles_x) * 8 + (threadIdx.x >> 4);
+    if (ox >= bw || oy >= bh) return;
     const int cx = ox + 6, cy = oy + 6;
     float     I = 1.0f - depthN[(size_t)cy * W + cx];
     I *= I;
-    float* o = out + 3 * idx;
+    float* o = out + 3 * ((size_t)oy * bw + ox);
     if (I >= 1.0f) { // identity kernel
         const float* p = rgb + 3 * ((size_t)cy * W + cx);
         o[0] = p[0], o[1] = p[1], o[2] = p[2];
@@ -324,15 +328,17 @@ k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int 
     for (int i = 0; i < 13; ++i)
         for (int j = 0; j < 13; ++j)
             total += tab[(((i - 6) * (i - 6) + (j - 6) * (j - 6)) >> 1) * DOF_BLOCK];
+    for (int k = 0; k < 37; ++k) tab[k * DOF_BLOCK] = __fdiv_rn(tab[k * DOF_BLOCK], total);
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (int j = 0; j < 13; ++j)
+    for (int j = 0; j < 13; ++j) {
+        const float* row = rgb + 3 * ((size_t)(cy + j - 6) * W + cx - 6);
         for (int k = 0; k < 13; ++k) {
-            const float  w = __fdiv_rn(tab[(((j - 6) * (j - 6) + (k - 6) * (k - 6)) >> 1) * DOF_BLOCK], total);
-            const float* p = rgb + 3 * ((size_t)(cy + j - 6) * W + cx + k - 6);
-            r += p[0] * w;
-            g += p[1] * w;
-            b += p[2] * w;
+            const float w = tab[(((j - 6) * (j - 6) + (k - 6) * (k - 6)) >> 1) * DOF_BLOCK];
+            r += row[3 * k] * w;
+            g += row[3 * k + 1] * w;
+            b += row[3 * k + 2] * w;
         }
+    }
     o[0] = r, o[1] = g, o[2] = b;
 }
 
@@ -1484,9 +1490,9 @@ extern "C" int rt_dof_blur_device(int device, int32_t W, int32_t H, float depth_
     if (W < 13 || H < 13 || W > 32768 || H > 32768)
         return fail(RT_ERR_INVALID, "rt_dof_blur: frame %dx%d must be at least 13x13", W, H);
     if (!d_rgb || !d_depth_n || !d_out) return fail(RT_ERR_INVALID, "rt_dof_blur: null argument");
-    const long long n = (long long)(W - 12) * (H - 12);
-    hipLaunchKernelGGL(k_dof_blur, dim3(blocks_for(n, DOF_BLOCK)), dim3(DOF_BLOCK), 0,
-                       (hipStream_t)stream, d_rgb, d_depth_n, (int)W, (int)H, depth_power, d_out);
+    const unsigned n_blocks = (unsigned)(((W - 12 + 15) / 16) * ((H - 12 + 7) / 8));
+    hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, (hipStream_t)stream, d_rgb,
+                       d_depth_n, (int)W, (int)H, depth_power, d_out);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -242,3 +242,33 @@ def test_trace_rays_k_and_prev_ni(P, oracle):
         L.or_perform_ray_tracing(s.h, o[i].ctypes.data, d[i].ctypes.data, 4, 1.0, C.byref(mt),
                                  ref[i].ctypes.data, None)
         assert np.abs(ref[i] - last[i]).max() < 1e-5
+
+
+def test_render_paths_agree(P, oracle, monkeypatch):
+    """The three frame renderers the library holds: the single persistent launch (default),
+    one launch per stage (RT_WF_MULTILAUNCH=1) and the per-sample kernels
+    (RT_MEGAKERNEL=1).  The first two accumulate in order-free fixed point and must agree
+    bit for bit; the third sums in float."""
+    hs, gs, m, lights = _host_gpu(P, "refractionballs")
+    W, H = 192, 108
+    corners = P.host.camera_corners(m, W, H)
+    frames = {}
+    for name, env in [("pipeline", {}), ("multilaunch", {"RT_WF_MULTILAUNCH": "1"}),
+                      ("megakernel", {"RT_MEGAKERNEL": "1"}), ("region512", {"RT_WF_REGION": "512"})]:
+        for k in ("RT_WF_MULTILAUNCH", "RT_MEGAKERNEL", "RT_WF_REGION"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        frames[name] = gs.render(corners, lights, P.capi.default_params(W, H, 4))
+    for k in ("RT_WF_MULTILAUNCH", "RT_MEGAKERNEL", "RT_WF_REGION"):
+        monkeypatch.delenv(k, raising=False)
+    a = frames["pipeline"]
+    for other in ("multilaunch", "region512"):
+        b = frames[other]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3].rays_closest == b[3].rays_closest and a[3].rays_shadow == b[3].rays_shadow
+    c = frames["megakernel"]
+    assert np.array_equal(a[2], c[2]) and np.array_equal(a[1], c[1])
+    d = np.abs(oracle.to_bytes(a[0]).astype(int) - oracle.to_bytes(c[0]).astype(int))
+    assert d.max() <= 1
+    assert a[3].rays_closest == c[3].rays_closest
