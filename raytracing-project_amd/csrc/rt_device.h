@@ -131,6 +131,17 @@ struct HitRec {
 // out.  det(P0,P1,P2) = P0x*P1y*P2z + P1x*P2y*P0z + P2x*P0y*P1z
 //                     - P0z*P1y*P2x - P1z*P2y*P0x - P2z*P0y*P1x,
 // every triple product as (x*y)*z and the sum left to right.
+//
+// The reference evaluates a, b, t in full and then rejects on
+// a < 0 || b < 0 || a + b > 1 || t < 0 || t > minT.  Most tests end in a rejection, and
+// a rejection can usually be proven from the numerators alone: a correctly rounded
+// quotient has the sign of the exact one unless it underflows, and it exceeds a bound
+// whenever the numerator exceeds bound * |D| by more than a few ulps.  So the numerators
+// are evaluated one at a time (each in the reference's operation order) and the test
+// returns as soon as one of these certain rejections applies; the divisions are reached
+// only by tests that are hits or lie within 1e-5 of an edge.  Whatever is not certain
+// falls through to the full evaluation, so the outcome is the reference's in every case
+// (finite inputs assumed: a NaN numerator would slip through the reference's comparisons).
 __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, f3 o,
                                          f3 d, float minT, float& a, float& b, float& t)
 {
@@ -139,17 +150,43 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     const float p1 = q2.y, p4 = q2.z; // e1x*e2y, e1z*e2y
     const float e2x_dy = e2x * d.y, dx_e1y = d.x * e1y, e2z_dy = e2z * d.y, dz_e1y = d.z * e1y;
     const float D = p1 * d.z + e2x_dy * e1z + dx_e1y * e2z - p4 * d.x - e2z_dy * e1x - dz_e1y * e2x;
+    const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
+                     e2z_dy * cx - (d.z * cy) * e2x;
+#ifndef RT_TRI_NO_STAGES
+    // |D| in [2^-40, 2^40] and |numerator| >= 2^-80 keep every quotient below clear of underflow
+    const float aD = fabsf(D);
+    const bool  Dok = aD >= 9.094947e-13f && aD <= 1.0995116e12f;
+    const float tiny = 8.271806e-25f;   // 2^-80
+    const float aDm = aD * 1.00001f;    // |n| > aDm  =>  |n / D| > 1 after rounding
+    const int   sD = __float_as_int(D);
+    if (Dok) {
+        const bool negA = (__float_as_int(da) ^ sD) < 0; // da / D < 0
+        if (negA ? fabsf(da) >= tiny : fabsf(da) > aDm) return false; // a < 0, or a > 1 (then b < 0 or a + b > 1)
+    }
+#endif
+    const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
+                     (cz * d.y) * e1x - dz_e1y * cx;
+#ifndef RT_TRI_NO_STAGES
+    if (Dok) {
+        const bool negB = (__float_as_int(db) ^ sD) < 0;
+        if (negB && fabsf(db) >= tiny) return false; // b < 0
+        // here a >= 0 or a is tiny, b likewise: a + b > 1 for certain when (da + db) / D clears 1
+        if (!negB && (__float_as_int(da) ^ sD) >= 0 && fabsf(da + db) > aDm) return false;
+    }
+#endif
+    const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
+                     (cz * e1y) * e2x;
+#ifndef RT_TRI_NO_STAGES
+    if (Dok) {
+        const bool posQ = (__float_as_int(dt) ^ sD) >= 0; // dt / D > 0, i.e. t = -(dt / D) < 0
+        if (fabsf(dt) >= tiny && (posQ || fabsf(dt) > minT * aDm)) return false; // t < 0, or t > minT
+    }
+#endif
     if (D == 0.0f) { // Matrix33.h:132-134: solve() returns (0,0,0); t = -0.0f
         a = 0.0f;
         b = 0.0f;
         t = -0.0f;
     } else {
-        const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
-                         e2z_dy * cx - (d.z * cy) * e2x;
-        const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
-                         (cz * d.y) * e1x - dz_e1y * cx;
-        const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
-                         (cz * e1y) * e2x;
         float q;
         div3_rn(da, db, dt, D, a, b, q);
         t = -q;
