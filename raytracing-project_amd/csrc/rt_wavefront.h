@@ -435,6 +435,12 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                 float angle;
                 cast = wf_light_setup(s, mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
                                       lightDir, angle, shadowMax);
+                // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
+                // shadowMax is its value with every query so far answered "free"; if that is 1
+                // already - set by a grazing angle at this light, or carried from an earlier one -
+                // the answer cannot change the colour and the query is not traced.
+                if (shadowMax == 1.0f) cast = false;
+                shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax;
             }
             const int pos = wf_append(&s_sh[li], cast);
             if (cast) {

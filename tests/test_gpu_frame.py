@@ -179,13 +179,16 @@ def test_full_size_frames_against_sparse_fixture(P, oracle, key):
     assert (rgb >= 0).all() and (rgb <= 1).all()                 # RGBValue clamp
     assert (rgb[tri < 0] == np.float32([0.2, 0.5, 1.0])).all()    # misses are background
     assert (depth[tri < 0] == FLT_MAX).all()
-    # the GPU skips the discarded centre-ray subtrees and traces shadows any-hit:
-    # fewer queries than the reference's count, never more
+    # the GPU skips the discarded centre-ray subtrees and the shadow queries whose answer
+    # cannot change shadowMax: fewer queries than the reference's count, never more; the
+    # closest-hit queries (one per ray of the tree) are all traced
     ref_rays = cfg["frame"]["rays_closest"] + cfg["frame"]["rays_shadow"]
     gpu_rays = st.rays_closest + st.rays_shadow
     assert gpu_rays <= ref_rays
     if cfg["msaa"] == 1:
-        assert gpu_rays >= 0.95 * ref_rays
+        # (a hit the reference's walk steps past, KDtree.cpp:288-587, changes a ray tree here and there)
+        assert abs(st.rays_closest - cfg["frame"]["rays_closest"]) <= 1e-4 * cfg["frame"]["rays_closest"]
+        assert 0.4 * cfg["frame"]["rays_shadow"] <= st.rays_shadow <= cfg["frame"]["rays_shadow"]
 
 
 def test_bad_arguments_are_rejected(P):
