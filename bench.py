@@ -18,7 +18,8 @@ divided by its duration from HIP events recorded inside the timed loop; the FLOP
 count is F = 45 T + 40 S + 30 H + 60 Hl + 25 C with the counters of the
 reference's algorithm (tests/golden/frame_counters.json, produced by
 tools/make_counters.py and tools/make_centre_primary.py on the CPU oracle), less
-the shading of the pixel-centre rays, whose colour the reference discards.
+the work whose result the reference never uses (shading of the pixel-centre
+rays, shadow queries that cannot change shadowMax).
 """
 import argparse
 import importlib
@@ -195,9 +196,11 @@ def main():
         if os.path.exists(fc_path) and kt.frames > 0:
             fc = json.load(open(fc_path)).get(key)
             if fc:
-                # the reference also shades every pixel-centre ray and discards the colour
-                # (main.cpp:439-445); flops_needed leaves that discarded work out, flops_frame is
-                # the reference's walk as it stands.  The headline figure uses the smaller one.
+                # flops_frame is the reference's walk as it stands.  Part of it never reaches the
+                # image: the reference shades every pixel-centre ray and discards the colour
+                # (main.cpp:439-445), and it traces shadow queries whose answer cannot change
+                # shadowMax (raytracing.cpp:127-143).  flops_needed leaves both out; the headline
+                # figure uses it, the figure for the full walk is reported next to it.
                 f_needed = fc.get("flops_needed", fc["flops_frame"])
                 f_kernel = f_needed / world
                 kern_ms = kt.frame_ms / kt.frames
@@ -214,7 +217,7 @@ def main():
                         "traffic": traffic, "kernel_ms": round(kern_ms, 3),
                         "launches_per_frame": round(kt.frames / args.steps, 2),
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
-                        "frac_incl_discarded_centre_shading": round(
+                        "frac_reference_walk": round(
                             fc["flops_frame"] / world / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                         "note": "no MFMA on this path: the bound is the FP32 vector peak (= the f32 MFMA "
                                 "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk "

@@ -28,6 +28,7 @@ class Settings(C.Structure):
 COUNTER_FIELDS = [
     "rays_closest", "rays_shadow", "tri_tests", "leaf_steps", "shaded_hits",
     "hit_lights", "child_rays", "camera_rays", "walk_guard",
+    "moot_shadow_rays", "moot_tri_tests", "moot_leaf_steps",
 ]
 
 
@@ -41,6 +42,10 @@ class Counters(C.Structure):
         """Algorithmic flops F = 45 T + 40 S + 30 H + 60 Hl + 25 C."""
         return (45 * self.tri_tests + 40 * self.leaf_steps + 30 * self.shaded_hits
                 + 60 * self.hit_lights + 25 * self.child_rays)
+
+    def flops_moot(self):
+        """The part of flops() spent on shadow queries whose answer cannot change the colour."""
+        return 45 * self.moot_tri_tests + 40 * self.moot_leaf_steps
 
 
 def build(force=False):

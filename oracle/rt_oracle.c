@@ -951,6 +951,7 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
     float shadowPart = s->set.ShadowFactor / s->nl;
     v3    shadowRGB = vscale(v3m(1.f, 1.f, 1.f), shadowPart);
     float shadowMax = 0.f;
+    float smFree = 0.f; /* counters only: shadowMax if every query so far found the light free */
     v3    viewDir = vsub(origin, hitPoint);
     vnormalize(&viewDir);
 
@@ -962,10 +963,10 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
         float angle = vdot(N, lightDir);
         if (angle > 0) resCol = vadd(resCol, vscale(vscale(v3ld(mat->Kd), angle), s->set.diffusePower));
         angle = vdot(lightDir, N);
-        if (angle <= 0.2f) shadowMax = 1.f;
+        if (angle <= 0.2f) shadowMax = smFree = 1.f;
         else if ((angle > 0.2f) & (angle < 0.5f)) {
             angle -= 0.2f;
-            shadowMax = (3.33f * (0.3f - angle));
+            shadowMax = smFree = (3.33f * (0.3f - angle));
         }
         float softShadow = 0.f;
         if (angle > 0.f) {
@@ -975,11 +976,18 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
             if (angle > 0.f) resCol = vadd(resCol, vscale(v3ld(mat->Ks), powf(angle, specularHighlight)));
             or_hit sh;
             v3 so = vadd(hitPoint, vscale(lightDir, 0.001f));
+            uint64_t t0 = c ? c->tri_tests : 0, s0 = c ? c->leaf_steps : 0;
             or_check_hit(s, so.p, lpos.p, &sh, c);
             if (c) c->rays_shadow++;
+            if (c && smFree == 1.f) {
+                c->moot_shadow_rays++;
+                c->moot_tri_tests += c->tri_tests - t0;
+                c->moot_leaf_steps += c->leaf_steps - s0;
+            }
             if (sh.bHit) shadowMax = 1.f;
         }
         shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax; /* std::max(shadowMax, softShadow) */
+        smFree = (smFree < softShadow) ? softShadow : smFree;
         resCol = vsub(resCol, vscale(shadowRGB, shadowMax));
     }
 

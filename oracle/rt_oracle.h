@@ -48,6 +48,11 @@ typedef struct or_counters {
     uint64_t child_rays;     /* C: reflection / refraction rays spawned */
     uint64_t camera_rays;    /* raytrace() calls of the frame driver */
     uint64_t walk_guard;     /* leaf walks stopped by the iteration guard */
+    /* Shadow queries whose answer cannot change the colour: shadowMax is 1 before the
+     * query whatever the earlier queries of this hit answered (raytracing.cpp:127-143).
+     * Included in rays_shadow / tri_tests / leaf_steps above; counted again here so the
+     * work that reaches the image can be stated separately. */
+    uint64_t moot_shadow_rays, moot_tri_tests, moot_leaf_steps;
 } or_counters;
 
 typedef struct or_hit {

@@ -411,6 +411,7 @@ struct RtScene {
     bool       refractive = false; // some material can spawn two child rays
     int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
+    void*      d_stk_spill = nullptr; // deep traversal stack entries of the wavefront kernels
     void*      wf_mem = nullptr;   // one allocation carved into the queues
     void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
     hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -468,7 +469,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -487,8 +488,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
     *out = nullptr;
     const int ndev = rt_device_count();
-    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
-    if (device < 0 || device >= ndev)
+    const bool stats_only = getenv("RT_KD_STATS") != nullptr; // tree diagnostics run without a GPU
+    if (ndev <= 0 && !stats_only) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
+    if (!(stats_only && ndev <= 0) && (device < 0 || device >= ndev))
         return fail(RT_ERR_INVALID, "rt_scene_create: device %d out of range (0..%d)", device, ndev - 1);
     const int nv = desc->n_vertices, nt = desc->n_triangles, nn = desc->n_nodes,
               nm = desc->n_materials, ntc = desc->n_texcoords, ntex = desc->n_textures,
@@ -750,6 +752,25 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     if (max_depth + 1 > 64)
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: KD tree depth %d exceeds 63", max_depth);
 
+    if (getenv("RT_KD_STATS")) { // diagnostic: how often each triangle is listed
+        std::vector<int> refs((size_t)std::max(nt, 1), 0);
+        size_t           total = 0, leaves = 0;
+        for (size_t k = 0; k < lists.size(); ++k) {
+            if (new_left[k] < 0) ++leaves;
+            for (int t : lists[k]) ++refs[t], ++total;
+        }
+        std::vector<int> idx((size_t)nt);
+        for (int t = 0; t < nt; ++t) idx[t] = t;
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return refs[a] > refs[b]; });
+        fprintf(stderr, "kd stats: %zu nodes, %zu leaves, %zu triangle references for %d triangles\n",
+                lists.size(), leaves, total, nt);
+        size_t cum = 0;
+        for (int i = 0; i < std::min(nt, 24); ++i) {
+            cum += refs[idx[i]];
+            fprintf(stderr, "  tri %d: %d leaves (cumulative %.1f%%)\n", idx[i], refs[idx[i]], 100.0 * cum / total);
+        }
+    }
+    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
     std::vector<DNode>  nodes(lists.size());
     std::vector<float4> slots;
     for (size_t k = 0; k < lists.size(); ++k) {
@@ -1090,6 +1111,7 @@ static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
 // ---------------------------------------------------------------------------
 // wavefront renderer (rt_wavefront.h)
 // ---------------------------------------------------------------------------
+#define WF_STACK_LDS 16 // traversal stack entries per thread kept in LDS
 #define WF_WORKSPACE_BUDGET ((size_t)12 << 30) // bytes of queues per scene at most
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1097,16 +1119,31 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int wf_prepare(RtScene* s)
 {
     if (s->wf_grid_trace) return RT_OK;
-    s->wf_lds = (size_t)s->d.stack_entries * WF_BLOCK * sizeof(unsigned short);
+    // LDS holds the first WF_STACK_LDS entries of every thread's traversal stack (fewer if the
+    // tree is shallower); the rest of the tree's depth is backed by a buffer in HBM that is
+    // touched only by the rare ray with that many far children pending.
+    const char* cap_env = getenv("RT_WF_STACK_LDS");
+    int         cap = cap_env ? atoi(cap_env) : WF_STACK_LDS;
+    cap = std::max(1, std::min(cap, (int)s->d.stack_entries));
+    s->d.stk_cap = cap;
+    s->wf_lds = (size_t)cap * WF_BLOCK * sizeof(unsigned short);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<false>, WF_BLOCK, s->wf_lds));
-    s->wf_grid_trace = std::max(1, per_cu) * prop.multiProcessorCount;
+    const int g_trace = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<true>, WF_BLOCK, s->wf_lds));
-    s->wf_grid_any = std::max(1, per_cu) * prop.multiProcessorCount;
+    const int g_any = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline, WF_BLOCK, s->wf_lds));
-    s->wf_grid_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
+    const int g_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
+    if (getenv("RT_KD_STATS"))
+        fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
+                (int)s->d.stack_entries, cap, s->wf_lds, per_cu);
+    const size_t deep = (size_t)(s->d.stack_entries - cap);
+    const size_t blocks = (size_t)std::max(g_trace, std::max(g_any, g_pipe));
+    HIP_TRY(hipMalloc(&s->d_stk_spill, std::max<size_t>(deep * blocks * WF_BLOCK * sizeof(unsigned short), 256)));
+    s->d.stk_spill = (unsigned short*)s->d_stk_spill;
+    s->wf_grid_trace = g_trace, s->wf_grid_any = g_any, s->wf_grid_pipe = g_pipe;
     return RT_OK;
 }
 

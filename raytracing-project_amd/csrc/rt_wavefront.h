@@ -133,8 +133,39 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int n_
 // margin; which triangle is hit, and where, is decided by tri_test alone.  The result
 // equals the reference's leaf walk (raytracing.cpp:281-351): the smallest t over all
 // triangles, ties to the triangle that walk would have tested last.
+// Per-thread traversal stack of node indices.  Entry e of a thread sits at lds[e * WF_BLOCK]
+// while e < cap, else at spill[(e - cap) * WF_BLOCK].  Rays rarely have more than a dozen
+// far children pending, so a short LDS part serves nearly all pushes and pops while the
+// tree's full depth stays available; LDS per block, and with it the number of resident
+// waves, no longer grows with the depth of the tree.
+struct WfStack {
+    unsigned short* lds;
+    unsigned short* spill;
+    int             cap;
+};
+
+__device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_mem)
+{
+    WfStack k;
+    k.lds = (unsigned short*)s_mem + threadIdx.x;
+    k.cap = S.stk_cap;
+    k.spill = S.stk_spill + (size_t)blockIdx.x * (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK + threadIdx.x;
+    return k;
+}
+
+__device__ __forceinline__ void wf_stk_put(const WfStack& k, int e, int node)
+{
+    if (e < k.cap) k.lds[e * WF_BLOCK] = (unsigned short)node;
+    else k.spill[(size_t)(e - k.cap) * WF_BLOCK] = (unsigned short)node;
+}
+
+__device__ __forceinline__ int wf_stk_get(const WfStack& k, int e)
+{
+    return e < k.cap ? k.lds[e * WF_BLOCK] : k.spill[(size_t)(e - k.cap) * WF_BLOCK];
+}
+
 template <bool ANY>
-__device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk, f3 o, f3 d, HitRec& h,
+__device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
 {
     float minT = RT_FLT_MAX;
@@ -150,9 +181,16 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk
                 iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
     const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
     const unsigned dpos = (ix > 0.0f ? 1u : 0u) | (iy > 0.0f ? 2u : 0u) | (iz > 0.0f ? 4u : 0u);
+#if defined(WF_MAILBOX_PROBE)
+    int mb[WF_MAILBOX_PROBE];
+    for (int m = 0; m < WF_MAILBOX_PROBE; ++m) mb[m] = -1;
+#define WF_COUNT_NODE(x)
+#else
+#define WF_COUNT_NODE(x) ++x
+#endif
     for (;;) {
         uint2 nd = S.knodes[node];
-        ++n_nodes;
+        WF_COUNT_NODE(n_nodes);
         while ((nd.y >> 30) != 3u) {
             const unsigned axis = nd.y >> 30;
             const int      left = (int)(nd.y & 0x3fffffffu);
@@ -167,13 +205,13 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk
             } else if (tplane < tmin_e) {
                 node = left + (below ? 1 : 0);
             } else {
-                stk[sp * WF_BLOCK] = (unsigned short)node;
+                wf_stk_put(stk, sp, node);
                 ++sp;
                 node = near;
                 tmax_e = tplane * (1.0f + RT_TRAV_EPS);
             }
             nd = S.knodes[node];
-            ++n_nodes;
+            WF_COUNT_NODE(n_nodes);
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
         const int first = (int)nd.x;
@@ -182,6 +220,16 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
             float        a, b, t;
             ++n_tests;
+#if defined(WF_MAILBOX_PROBE) // diagnostic build: node_visits counts re-tests of a recently tested triangle
+            {
+                const int id = __float_as_int(q2.w);
+                bool      rep = false;
+                for (int m = 0; m < WF_MAILBOX_PROBE; ++m) rep |= mb[m] == id;
+                if (rep) ++n_nodes;
+                for (int m = WF_MAILBOX_PROBE - 1; m > 0; --m) mb[m] = mb[m - 1];
+                mb[0] = id;
+            }
+#endif
 #if defined(WF_ABLATE_DOUBLE_TEST) // timing experiment: the arithmetic of the test a second time
             {
                 float a2, b2, t2;
@@ -209,7 +257,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk
         bool found = false;
         while (sp > 0) {
             --sp;
-            const uint2    pn = S.knodes[stk[sp * WF_BLOCK]];
+            const uint2    pn = S.knodes[wf_stk_get(stk, sp)];
             const unsigned axis = pn.y >> 30;
             const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
             const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
@@ -220,7 +268,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, unsigned short* stk
             tmin_e = et * (1.0f - RT_TRAV_EPS);
             tmax_e = RT_FLT_MAX;
             if (sp > 0) {
-                const uint2    qn = S.knodes[stk[(sp - 1) * WF_BLOCK]];
+                const uint2    qn = S.knodes[wf_stk_get(stk, sp - 1)];
                 const unsigned qa = qn.y >> 30;
                 const float    qi = qa == 0 ? ix : (qa == 1 ? iy : iz);
                 const float    qo = qa == 0 ? oix : (qa == 1 ? oiy : oiz);
@@ -256,7 +304,7 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
            int* head, float4* hits, unsigned char* occl, DCounters* ctr)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
-    unsigned short* stk = (unsigned short*)s_mem + threadIdx.x;
+    const WfStack   stk = wf_stack(S, s_mem);
     const int       total = prefix[n_regions];
     const int       lane = threadIdx.x & 63;
     unsigned        n_tests = 0, n_nodes = 0, n_rays = 0;
@@ -740,7 +788,7 @@ template <bool ANY>
 __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* __restrict__ o_w,
                                                 const float4* __restrict__ d_ni, f3 light, int n,
                                                 size_t base, float4* hits, unsigned char* occl,
-                                                unsigned short* stk, unsigned& n_tests, unsigned& n_nodes,
+                                                const WfStack& stk, unsigned& n_tests, unsigned& n_nodes,
                                                 unsigned& n_rays)
 {
     for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
@@ -771,7 +819,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
     __shared__ WfShared sh;
-    unsigned short*     stk = (unsigned short*)s_mem + threadIdx.x;
+    const WfStack       stk = wf_stack(S, s_mem);
     unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0;
     const size_t        ns = (size_t)B.n_samples;
     for (;;) {

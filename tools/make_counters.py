@@ -5,8 +5,13 @@ Writes
   tests/golden/frame_counters.json  - per config the work counters of the
       reference's algorithm (ray counts, T = ray/triangle tests, S = leaf steps,
       H, Hl, C), for the whole frame and for the pixel-centre rays alone, and
-      the algorithmic flops F = 45 T + 40 S + 30 H + 60 Hl + 25 C that
-      bench.py's roofline figure is computed from;
+      the algorithmic flops F = 45 T + 40 S + 30 H + 60 Hl + 25 C
+      (flops_frame).  The reference spends part of F on results it never uses:
+      with MSAA it shades the pixel-centre ray and throws the colour away when
+      the centre hits (main.cpp:439-445; only that ray's closest-hit query,
+      counted in centre_primary, decides anything), and it traces shadow
+      queries whose answer cannot change shadowMax (counted in moot_*).
+      flops_needed = F less both, the figure bench.py's roofline uses;
   tests/golden/sparse_<config>.npz  - 20000 seeded pixels of each full-size
       frame (x, y, primary triangle, 8-bit RGB, depth) for spot checks of
       full-resolution GPU frames.
@@ -32,6 +37,33 @@ CONFIGS = [
 ]
 
 
+def pixel_rays(corners, W, H, x, y):
+    """or_pixel_ray for arrays of pixel coordinates (float32 arithmetic, same order)."""
+    f = np.float32
+    xsc = 1.0 - x.astype(np.float64) / (W - 1)
+    ysc = 1.0 - y.astype(np.float64) / (H - 1)
+    xs, xs1, ys, ys1 = (v.astype(f)[:, None] for v in (xsc, 1 - xsc, ysc, 1 - ysc))
+    o00, d00, o01, d01, o10, d10, o11, d11 = np.asarray(corners, f).reshape(8, 3)
+
+    def mix(a00, a10, a01, a11):
+        return (a00 * xs + a10 * xs1) * ys + (a01 * xs + a11 * xs1) * ys1
+    return mix(o00, o10, o01, o11).astype(f), mix(d00, d10, d01, d11).astype(f)
+
+
+def centre_primary(s, corners, W, H, threads):
+    """Counters of the closest-hit queries of the pixel-centre rays alone."""
+    o1, d1 = pixel_rays(corners, W, H, np.array([17, W - 3]), np.array([H - 5, 11]))
+    for i, (x, y) in enumerate(((17, H - 5), (W - 3, 11))):  # the vector form equals the oracle's
+        o0, d0 = O.pixel_ray(corners, W, H, x, y)
+        assert (o0 == o1[i]).all() and (d0 == d1[i]).all()
+    c = O.Counters()
+    for y0 in range(0, H, 135):
+        ys, xs = np.mgrid[y0:min(y0 + 135, H), 0:W]
+        o, d = pixel_rays(corners, W, H, xs.ravel(), ys.ravel())
+        s.check_hits(o, d, threads=threads, counters=c)
+    return c
+
+
 def main():
     threads = int(os.environ.get("THREADS", "8"))
     only = sys.argv[1:]
@@ -54,6 +86,12 @@ def main():
                         frame=c.as_dict(), centre=cen.as_dict(), flops_frame=c.flops(),
                         flops_centre=cen.flops(), oracle_seconds=round(dt, 2), oracle_threads=threads,
                         hit_fraction=float((tri >= 0).mean()))
+        needed = c.flops() - c.flops_moot()
+        if msaa > 1:
+            cp = centre_primary(s, corners, W, H, threads)
+            out[key].update(centre_primary=cp.as_dict(), flops_centre_primary=cp.flops())
+            needed += cp.flops() - (cen.flops() - cen.flops_moot())
+        out[key].update(flops_moot=c.flops_moot(), flops_needed=needed)
         rng = np.random.Generator(np.random.PCG64(1806))
         idx = rng.choice(W * H, 20000, replace=False)
         ys, xs = idx // W, idx % W
