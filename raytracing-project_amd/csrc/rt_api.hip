@@ -292,51 +292,82 @@ __global__ void k_depth_normalize(float* depth, long long n, const float* __rest
 // ---- depth-of-field blur, imageWriter.h:137-231 ----
 // The 13x13 kernel of a pixel depends on (i-6)^2 + (j-6)^2 only through
 // -((..)/2) with integer division, i.e. 37 possible exponents.  Each thread
-// evaluates those 37 powf once into an LDS table, walks the 169 taps in the
-// reference's order to form the normalisation sum (the float sum depends on
-// the order), divides the 37 table entries by it (the same operands as the 169
-// divisions of the reference, hence the same weights) and gathers.
-#define DOF_BLOCK 128
+// evaluates those 37 powers once into registers (the tap loops are fully
+// unrolled, so every table index is a compile-time constant), walks the 169
+// taps in the reference's order to form the normalisation sum (the float sum
+// depends on the order), divides the 37 entries by it (the same operands as
+// the 169 divisions of the reference, hence the same weights) and gathers from
+// an LDS copy of the block's 44x20 pixel neighbourhood.
+#define DOF_TW 32
+#define DOF_TH 8
+#define DOF_BLOCK (DOF_TW * DOF_TH)
+#define DOF_LW (DOF_TW + 12)
+#define DOF_LH (DOF_TH + 12)
+
+// powf(e, x) for the float e = 2.7182817459106445 and x <= 0 (imageWriter.h:165-168):
+// 2^(x * log2 e) with the product carried in two floats and the hardware exp2 (about one
+// ulp); results below the normal range go through a 2^64 rescale so they come out as the
+// denormals (or the zero) powf returns there.  Within 2 ulp of the correctly rounded value.
+__device__ __forceinline__ float dof_pow_e(float x)
+{
+    const float Lh = 1.4426950216293335f, Ll = -2.4551930266625277e-08f; // log2(e), hi + lo
+    const float th = x * Lh;
+    const float tl = __builtin_fmaf(x, Lh, -th) + x * Ll;
+    const bool  small = th < -120.0f;
+    float       r = __builtin_amdgcn_exp2f(small ? th + 64.0f : th);
+    r = __builtin_fmaf(r, tl * 0.6931471805599453f, r);
+    return small ? r * 5.421010862427522e-20f : r; // 2^-64
+}
+
 __global__ void __launch_bounds__(DOF_BLOCK)
 k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int W, int H,
            float depthPower, float* out)
 {
-    __shared__ float s_tab[37 * DOF_BLOCK];
-    const int        bw = W - 12, bh = H - 12;
-    // 16 x 8 pixel blocks: neighbouring threads share most of their taps' cache lines
-    const int tiles_x = (bw + 15) >> 4;
-    const int ox = (blockIdx.x % tiles_x) * 16 + (threadIdx.x & 15);
-    const int oy = (blockIdx.x / tiles_x) * 8 + (threadIdx.x >> 4);
+    __shared__ float4 s_px[DOF_LH * DOF_LW];
+    const int bw = W - 12, bh = H - 12;
+    const int tiles_x = (bw + DOF_TW - 1) / DOF_TW;
+    const int x0 = (blockIdx.x % tiles_x) * DOF_TW, y0 = (blockIdx.x / tiles_x) * DOF_TH;
+    for (int i = threadIdx.x; i < DOF_LH * DOF_LW; i += DOF_BLOCK) {
+        const int ly = i / DOF_LW, lx = i - ly * DOF_LW;
+        const int gx = min(x0 + lx, W - 1), gy = min(y0 + ly, H - 1); // clamped reads feed no written pixel
+        const float* p = rgb + 3 * ((size_t)gy * W + gx);
+        s_px[i] = make_float4(p[0], p[1], p[2], 0.0f);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % DOF_TW, ty = threadIdx.x / DOF_TW;
+    const int ox = x0 + tx, oy = y0 + ty;
     if (ox >= bw || oy >= bh) return;
-    const int cx = ox + 6, cy = oy + 6;
-    float     I = 1.0f - depthN[(size_t)cy * W + cx];
+    float I = 1.0f - depthN[(size_t)(oy + 6) * W + ox + 6];
     I *= I;
     float* o = out + 3 * ((size_t)oy * bw + ox);
     if (I >= 1.0f) { // identity kernel
-        const float* p = rgb + 3 * ((size_t)cy * W + cx);
-        o[0] = p[0], o[1] = p[1], o[2] = p[2];
+        const float4 c = s_px[(ty + 6) * DOF_LW + tx + 6];
+        o[0] = c.x, o[1] = c.y, o[2] = c.z;
         return;
     }
-    float*       tab = s_tab + threadIdx.x;
     const float  idp = I * depthPower;
-    const float  p2 = powf(idp, 2.0f);
+    const float  p2 = idp * idp; // powf(x, 2) is the correctly rounded square
     const double c1 = 1.0 / ((double)(idp * 2.0f) * 3.14159265358979323846);
-    const float  e = (float)2.71828182845904523536;
-    for (int k = 0; k < 37; ++k)
-        tab[k * DOF_BLOCK] = (float)(c1 * (double)powf(e, (float)(-k) * p2));
+    float        tab[37];
+#pragma unroll
+    for (int k = 0; k < 37; ++k) tab[k] = (float)(c1 * (double)dof_pow_e((float)(-k) * p2));
     float total = 0.0f;
+#pragma unroll
     for (int i = 0; i < 13; ++i)
-        for (int j = 0; j < 13; ++j)
-            total += tab[(((i - 6) * (i - 6) + (j - 6) * (j - 6)) >> 1) * DOF_BLOCK];
-    for (int k = 0; k < 37; ++k) tab[k * DOF_BLOCK] = __fdiv_rn(tab[k * DOF_BLOCK], total);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) total += tab[((i - 6) * (i - 6) + (j - 6) * (j - 6)) >> 1];
+#pragma unroll
+    for (int k = 0; k < 37; ++k) tab[k] = __fdiv_rn(tab[k], total);
     float r = 0.0f, g = 0.0f, b = 0.0f;
+#pragma unroll
     for (int j = 0; j < 13; ++j) {
-        const float* row = rgb + 3 * ((size_t)(cy + j - 6) * W + cx - 6);
+#pragma unroll
         for (int k = 0; k < 13; ++k) {
-            const float w = tab[(((j - 6) * (j - 6) + (k - 6) * (k - 6)) >> 1) * DOF_BLOCK];
-            r += row[3 * k] * w;
-            g += row[3 * k + 1] * w;
-            b += row[3 * k + 2] * w;
+            const float  w = tab[((j - 6) * (j - 6) + (k - 6) * (k - 6)) >> 1];
+            const float4 c = s_px[(ty + j) * DOF_LW + tx + k];
+            r += c.x * w;
+            g += c.y * w;
+            b += c.z * w;
         }
     }
     o[0] = r, o[1] = g, o[2] = b;
@@ -644,6 +675,24 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             const double r = h[0] * std::fabs(nrm[0]) + h[1] * std::fabs(nrm[1]) + h[2] * std::fabs(nrm[2]);
             return std::fabs(d) <= r + 1e-9 * (r + std::fabs(d));
         };
+        // RT_KD_REBUILD=1: drop the planes of the input tree and let the refinement below build
+        // the whole tree from one root leaf holding every listed triangle.
+        const char* rb_env = getenv("RT_KD_REBUILD");
+        if (rb_env && rb_env[0] == '1') {
+            std::vector<char> listed((size_t)nt, 0);
+            std::vector<int>  all;
+            for (auto& l : lists)
+                for (int t : l)
+                    if (!listed[t]) listed[t] = 1, all.push_back(t);
+            lists.assign(1, all);
+            new_left.assign(1, -1);
+            depth_of.assign(1, 0);
+            axis_of.assign(1, 0);
+            split_of.assign(1, 0.0f);
+            order.resize(1);
+            cell.resize(1);
+            max_depth = 0;
+        }
         for (size_t k = 0; k < order.size(); ++k) {
             if (new_left[k] < 0) continue;
             const int    axis = depth_of[k] % 3;
@@ -1134,7 +1183,7 @@ static int wf_prepare(RtScene* s)
     const int g_trace = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<true>, WF_BLOCK, s->wf_lds));
     const int g_any = std::max(1, per_cu) * prop.multiProcessorCount;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline, WF_BLOCK, s->wf_lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false>, WF_BLOCK, s->wf_lds));
     const int g_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
     if (getenv("RT_KD_STATS"))
         fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
@@ -1246,7 +1295,7 @@ static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hi
 // other (8 GPUs' share of a 4K frame: 7.8 ms with 1 pipeline, 8.6 / 9.9 / 12.5 ms with
 // 2 / 3 / 4), so the default is 1.
 static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, float* d_rgb, float* d_depth,
-                            int32_t* d_tri, hipStream_t user)
+                            int32_t* d_tri, hipStream_t user, bool count)
 {
     int rc = wf_prepare(s);
     if (rc) return rc;
@@ -1307,8 +1356,12 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         if (single) {
             hipStream_t st = s->wf_stream[0];
             HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
-            hipLaunchKernelGGL(k_wf_pipeline, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d, P, C[0],
-                               slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
+            if (count)
+                hipLaunchKernelGGL(k_wf_pipeline<true>, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d,
+                                   P, C[0], slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
+            else
+                hipLaunchKernelGGL(k_wf_pipeline<false>, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d,
+                                   P, C[0], slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1395,7 +1448,7 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
     const char* mk_env = getenv("RT_MEGAKERNEL");
     const bool  wavefront = s->pushdown && s->d.n_nodes < 65536 && !(mk_env && mk_env[0] == '1');
     if (n_slots > 0 && wavefront) {
-        if ((rc = render_wavefront(s, P, n_slots, d_rgb, d_depth, d_tri, stream))) return rc;
+        if ((rc = render_wavefront(s, P, n_slots, d_rgb, d_depth, d_tri, stream, stats != nullptr))) return rc;
     } else if (n_slots > 0) {
         if ((rc = ensure_workspace(s, n_slots, P.msaa))) return rc;
         const size_t lds = stack_bytes(s);
@@ -1527,7 +1580,7 @@ extern "C" int rt_dof_blur_device(int device, int32_t W, int32_t H, float depth_
     if (W < 13 || H < 13 || W > 32768 || H > 32768)
         return fail(RT_ERR_INVALID, "rt_dof_blur: frame %dx%d must be at least 13x13", W, H);
     if (!d_rgb || !d_depth_n || !d_out) return fail(RT_ERR_INVALID, "rt_dof_blur: null argument");
-    const unsigned n_blocks = (unsigned)(((W - 12 + 15) / 16) * ((H - 12 + 7) / 8));
+    const unsigned n_blocks = (unsigned)(((W - 12 + DOF_TW - 1) / DOF_TW) * ((H - 12 + DOF_TH - 1) / DOF_TH));
     hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, (hipStream_t)stream, d_rgb,
                        d_depth_n, (int)W, (int)H, depth_power, d_out);
     HIP_TRY(hipGetLastError());

@@ -164,7 +164,7 @@ __device__ __forceinline__ int wf_stk_get(const WfStack& k, int e)
     return e < k.cap ? k.lds[e * WF_BLOCK] : k.spill[(size_t)(e - k.cap) * WF_BLOCK];
 }
 
-template <bool ANY>
+template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
 {
@@ -180,25 +180,17 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 iy = d.y != 0.0f ? __builtin_amdgcn_rcpf(d.y) : big,
                 iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
     const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
-    const unsigned dpos = (ix > 0.0f ? 1u : 0u) | (iy > 0.0f ? 2u : 0u) | (iz > 0.0f ? 4u : 0u);
-#if defined(WF_MAILBOX_PROBE)
-    int mb[WF_MAILBOX_PROBE];
-    for (int m = 0; m < WF_MAILBOX_PROBE; ++m) mb[m] = -1;
-#define WF_COUNT_NODE(x)
-#else
-#define WF_COUNT_NODE(x) ++x
-#endif
     for (;;) {
         uint2 nd = S.knodes[node];
-        WF_COUNT_NODE(n_nodes);
+        if (COUNT) ++n_nodes;
         while ((nd.y >> 30) != 3u) {
             const unsigned axis = nd.y >> 30;
             const int      left = (int)(nd.y & 0x3fffffffu);
             const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
             const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
             const float    tplane = __builtin_fmaf(__uint_as_float(nd.x), ia, -oi);
-            // origin side of the plane: below it iff (split - o) > 0 iff tplane and d agree in sign
-            const bool below = (tplane > 0.0f) == (((dpos >> axis) & 1u) != 0u);
+            // origin side of the plane: below it iff (split - o) > 0 iff tplane and d (hence 1/d) agree in sign
+            const bool below = (tplane > 0.0f) == (ia > 0.0f);
             const int  near = left + (below ? 0 : 1);
             if (tplane <= 0.0f || !(tplane <= tmax_e)) {
                 node = near;
@@ -211,7 +203,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 tmax_e = tplane * (1.0f + RT_TRAV_EPS);
             }
             nd = S.knodes[node];
-            WF_COUNT_NODE(n_nodes);
+            if (COUNT) ++n_nodes;
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
         const int first = (int)nd.x;
@@ -219,17 +211,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const int    slot = first + i;
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
             float        a, b, t;
-            ++n_tests;
-#if defined(WF_MAILBOX_PROBE) // diagnostic build: node_visits counts re-tests of a recently tested triangle
-            {
-                const int id = __float_as_int(q2.w);
-                bool      rep = false;
-                for (int m = 0; m < WF_MAILBOX_PROBE; ++m) rep |= mb[m] == id;
-                if (rep) ++n_nodes;
-                for (int m = WF_MAILBOX_PROBE - 1; m > 0; --m) mb[m] = mb[m - 1];
-                mb[0] = id;
-            }
-#endif
+            if (COUNT) ++n_tests;
 #if defined(WF_ABLATE_DOUBLE_TEST) // timing experiment: the arithmetic of the test a second time
             {
                 float a2, b2, t2;
@@ -263,7 +245,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
             const float    et = __builtin_fmaf(__uint_as_float(pn.x), ia, -oi);
             if (!ANY && et * (1.0f - RT_TRAV_EPS) > minT) continue;
-            const bool below = (et > 0.0f) == (((dpos >> axis) & 1u) != 0u);
+            const bool below = (et > 0.0f) == (ia > 0.0f);
             node = (int)(pn.y & 0x3fffffffu) + (below ? 1 : 0);
             tmin_e = et * (1.0f - RT_TRAV_EPS);
             tmax_e = RT_FLT_MAX;
@@ -784,7 +766,7 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
 // is no device-wide synchronisation and no launch boundary inside the frame, so a CU
 // always has other blocks' stages to run while one block waits for its slowest ray, and
 // the bandwidth-bound stages of some blocks overlap the arithmetic-bound traces of others.
-template <bool ANY>
+template <bool ANY, bool COUNT>
 __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* __restrict__ o_w,
                                                 const float4* __restrict__ d_ni, f3 light, int n,
                                                 size_t base, float4* hits, unsigned char* occl,
@@ -802,7 +784,7 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
         }
         HitRec h;
         ++n_rays;
-        const bool got = wf_traverse<ANY>(S, stk, o, dst - o, h, n_tests, n_nodes);
+        const bool got = wf_traverse<ANY, COUNT>(S, stk, o, dst - o, h, n_tests, n_nodes);
         if (ANY) occl[__float_as_int(ow.w)] = got ? 1 : 0;
         else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
     }
@@ -813,6 +795,7 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
 #ifndef WF_PIPE_WAVES
 #define WF_PIPE_WAVES 7
 #endif
+template <bool COUNT>
 __global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
 k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* rgb, float* depth, int* tri,
               unsigned char* centre_hit, DCounters* ctr)
@@ -835,7 +818,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         }
         wf_gen_region(P, B, B.rays[0], slot0, n, ctr, r, &sh);
         __syncthreads();
-        wf_trace_region<false>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base, B.hits,
+        wf_trace_region<false, COUNT>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base, B.hits,
                                nullptr, stk, n_tests, n_nodes, n_closest);
         __syncthreads();
         int q0 = 0;
@@ -849,14 +832,14 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
             const int    n_in = in.cnt[r];
             if (n_in == 0) break;
             if (level > 0 || q0 == 1) {
-                wf_trace_region<false>(S, in.o_w, in.d_ni, mk3(0, 0, 0), n_in, base, B.hits, nullptr, stk,
+                wf_trace_region<false, COUNT>(S, in.o_w, in.d_ni, mk3(0, 0, 0), n_in, base, B.hits, nullptr, stk,
                                        n_tests, n_nodes, n_closest);
                 __syncthreads();
             }
             wf_shade_region(S, P, B, in, out, r, &sh);
             __syncthreads();
             for (int li = 0; li < P.n_lights; ++li)
-                wf_trace_region<true>(S, B.sh_org + (size_t)li * B.cap, nullptr,
+                wf_trace_region<true, COUNT>(S, B.sh_org + (size_t)li * B.cap, nullptr,
                                       mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
                                       B.sh_cnt[(size_t)li * B.G + r], base, nullptr,
                                       B.occl + (size_t)li * B.cap, stk, n_tests, n_nodes, n_shadow);

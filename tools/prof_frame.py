@@ -17,5 +17,16 @@ if _os.environ.get('WORLD'):
 for _ in range(frames):
     rgb, depth, tri, st = gs.render(corners, lights, p)
 rays = st.rays_closest + st.rays_shadow
+# the same frame without statistics, as bench.py times it: device buffers, HIP events around the launches
+import torch
+d_rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+d_depth = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+gs.set_timing(True)
+for _ in range(frames):
+    gs.render_device(corners, lights, p, d_rgb.data_ptr(), d_depth.data_ptr(), 0, 0, False)
+torch.cuda.synchronize()
+kt = gs.collect_timing()
+assert (d_rgb.cpu().numpy() == rgb).all()
+print(f"no-stats frame: {kt.frame_ms / max(kt.frames, 1):.2f} ms ({kt.frames} launches timed)")
 print(f"{name} {W}x{H} msaa{msaa}: {st.kernel_ms:.2f} ms, {rays/1e6:.1f} Mrays, {rays/st.kernel_ms/1e3:.0f} Mrays/s, "
       f"tests/ray {st.tri_tests/rays:.1f}, nodes/ray {st.node_visits/rays:.1f}, slots {gs.info()['n_slots']}")
