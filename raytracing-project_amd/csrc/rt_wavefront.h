@@ -236,6 +236,11 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 if (take) h.a = a, h.b = b, minT = t, best_orig = orig;
             }
         }
+        // A pending subtree starts where the cell above it on the stack ends, give or take the
+        // margins: entry t of the top entry = tmax_e / (1 + eps), and every deeper entry starts
+        // at most a factor (1 + eps) per level earlier.  A hit clearly inside the current cell
+        // therefore ends the walk without popping (and loading) the entries one by one.
+        if (!ANY && minT < tmax_e * 0.998f) break;
         bool found = false;
         while (sp > 0) {
             --sp;
