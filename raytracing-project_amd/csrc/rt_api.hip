@@ -1210,7 +1210,7 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
     const int       growth = s->refractive ? 16 : 1;
     const int       L = std::max(P.n_lights, 1);
     const long long R = (long long)S * P.msaa * growth;
-    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8) + 16 + 4 + (size_t)L * 17) +
+    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8 + 16) + 4 + (size_t)L * 17) +
                               (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
                               (size_t)(2 + 2 * (1 + L)) * 4;
     long long g_max = (long long)(WF_WORKSPACE_BUDGET / n_pipes / per_region);
@@ -1239,7 +1239,7 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
         need += align256(bytes);
     };
     for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 8), take(G * 4); // 0..7
-    take(cap * 16);                            // 8 hits
+    take(cap * 16 * 2);                        // 8 hits, one set per queue
     take(cap * 4);                             // 9 wlocal
     take(cap * 16 * (size_t)L);                // 10 sh_org
     take(G * 4 * (size_t)L);                   // 11 sh_cnt
@@ -1263,7 +1263,7 @@ static void wf_carve(unsigned char* m, const WfPlan& pl, WfBuffers* B, unsigned 
         B->rays[q].meta = (uint2*)(m + off[4 * q + 2]);
         B->rays[q].cnt = (int*)(m + off[4 * q + 3]);
     }
-    B->hits = (float4*)(m + off[8]);
+    for (int q = 0; q < 2; ++q) B->rays[q].hits = (float4*)(m + off[8]) + (size_t)q * pl.G * pl.R;
     B->wlocal = (float*)(m + off[9]);
     B->sh_org = (float4*)(m + off[10]);
     B->sh_cnt = (int*)(m + off[11]);
@@ -1284,7 +1284,7 @@ static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hi
     const int te = timing_begin(s, K_TRACE_CLOSEST, st);
     hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
                        (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
-                       (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.hits,
+                       (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.rays[q].hits,
                        (unsigned char*)nullptr, s->d_ctr);
     timing_end(s, te, st);
 }
@@ -1311,9 +1311,10 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     const bool  single = !(ml_env && ml_env[0] == '1');
     const char* rg_env = getenv("RT_WF_REGION");
     int         S = 512;
-    if (single) { // about 16 regions per resident block: 256 slots for a whole 4K frame, 64 for an eighth
+    if (single) { // measured on a 4K MSAA4 frame: 128 slots for the whole frame (12.3 ms; 256: 12.6, 64: 13.5),
+                  // 64 for an eighth of it (2.6 ms; 128: 3.0)
         const long long per_block = n_slots / (16LL * std::max(s->wf_grid_pipe, 1));
-        S = per_block >= 256 ? 256 : (per_block >= 128 ? 128 : 64);
+        S = per_block >= 512 ? 256 : (per_block >= 100 ? 128 : 64);
     }
     if (rg_env) S = atoi(rg_env);
     S = std::max(64, std::min(4096, (S / 64) * 64));

@@ -71,11 +71,12 @@ struct WfRays {
     float4* d_ni; // destination xyz, prev_Ni
     uint2*  meta; // x: sample index, y: k | shared << 8
     int*    cnt;  // [G] rays in each region
+    float4* hits; // per ray slot: bits(orig triangle or -1), a, b, t - one set per queue, so the
+                  // closest hits of a level can be traced while the level before is still resolved
 };
 
 struct WfBuffers {
     WfRays         rays[2];   // ping-pong between levels
-    float4*        hits;      // per ray slot: bits(orig triangle or -1), a, b, t
     float*         wlocal;    // per ray slot: weight of the hit's own colour (0 for a miss)
     float4*        sh_org;    // [light][cap]: shadow ray origin xyz, bits(ray slot)
     int*           sh_cnt;    // [light][G]
@@ -445,7 +446,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
         const size_t i = base + j;
         uint2        meta = make_uint2(0, 0);
         float4       ow = make_float4(0, 0, 0, 0), dn = make_float4(0, 0, 0, 0), hit = make_float4(0, 0, 0, 0);
-        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = B.hits[i];
+        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = in.hits[i];
         const int   orig = valid ? __float_as_int(hit.x) : -1;
         const int   k = (int)(meta.y & 0xff);
         bool        shared = (meta.y >> 8) & 1;
@@ -567,7 +568,7 @@ __device__ __forceinline__ void wf_resolve_region(const DScene& S, const DParams
     for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
         const size_t i = base + j;
         const float  wl = B.wlocal[i];
-        const float4 hit = B.hits[i];
+        const float4 hit = in.hits[i];
         if (__float_as_int(hit.x) < 0) continue;
         const uint2  meta = in.meta[i];
         const float4 ow = in.o_w[i], dn = in.d_ni[i];
@@ -670,7 +671,7 @@ __device__ __forceinline__ void wf_msaa_region(const DParams& P, const WfBuffers
         int        x = 0, y = 0, slot = 0;
         if (valid) {
             slot = (int)in.meta[base + j].x;
-            const float4 hit = B.hits[base + j];
+            const float4 hit = in.hits[base + j];
             got = __float_as_int(hit.x) >= 0;
             slot_to_pixel(P, slot0 + slot, x, y);
             const size_t p = (size_t)y * P.W + x;
@@ -795,6 +796,50 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
     }
 }
 
+// Shadow queries of one level and closest-hit queries of the next in one pass: both sets
+// of rays come out of the same shade stage and neither needs the other's answers, so a
+// region's chain of dependent stages is one trace per level instead of two.  The index
+// space is [closest rays][light 0][light 1]..., each segment padded to whole waves so a
+// wave runs one kind of walk; the closest-hit rays (the longer walks) start first.
+template <bool COUNT>
+__device__ __forceinline__ void wf_trace_merged(const DScene& S, const DParams& P, const WfBuffers& B,
+                                                const WfRays next, int n_next, int r, const WfStack& stk,
+                                                unsigned& n_tests, unsigned& n_nodes, unsigned& n_closest,
+                                                unsigned& n_shadow)
+{
+    const size_t base = (size_t)r * B.R;
+    const int    seg_c = (n_next + 63) & ~63;
+    int          total = seg_c;
+    for (int li = 0; li < P.n_lights; ++li) total += (B.sh_cnt[(size_t)li * B.G + r] + 63) & ~63;
+    for (int i = threadIdx.x; i < total; i += WF_BLOCK) {
+        if (i < seg_c) {
+            if (i >= n_next) continue;
+            const size_t k = base + i;
+            const float4 ow = next.o_w[k], dn = next.d_ni[k];
+            const f3     o = mk3(ow.x, ow.y, ow.z);
+            HitRec       h;
+            ++n_closest;
+            const bool got = wf_traverse<false, COUNT>(S, stk, o, mk3(dn.x, dn.y, dn.z) - o, h, n_tests, n_nodes);
+            next.hits[k] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
+        } else {
+            int j = i - seg_c, li = 0, n_li = B.sh_cnt[r];
+            while (j >= ((n_li + 63) & ~63)) { // wave-uniform: segments are whole waves
+                j -= (n_li + 63) & ~63;
+                ++li;
+                n_li = B.sh_cnt[(size_t)li * B.G + r];
+            }
+            if (j >= n_li) continue;
+            const float4 ow = B.sh_org[(size_t)li * B.cap + base + j];
+            const f3     o = mk3(ow.x, ow.y, ow.z);
+            const f3     l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
+            HitRec       h;
+            ++n_shadow;
+            const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, n_tests, n_nodes);
+            B.occl[(size_t)li * B.cap + __float_as_int(ow.w)] = got ? 1 : 0;
+        }
+    }
+}
+
 // Compiled for 7 waves per SIMD (72 VGPRs; what does not fit spills, outside the traversal
 // loops).  Measured per 4K frame: 25.6 / 23.6 / 23.3 / 22.6 / 25.4 ms for 4 / 5 / 6 / 7 / 8.
 #ifndef WF_PIPE_WAVES
@@ -823,33 +868,33 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         }
         wf_gen_region(P, B, B.rays[0], slot0, n, ctr, r, &sh);
         __syncthreads();
-        wf_trace_region<false, COUNT>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base, B.hits,
-                               nullptr, stk, n_tests, n_nodes, n_closest);
+        wf_trace_region<false, COUNT>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base,
+                                      B.rays[0].hits, nullptr, stk, n_tests, n_nodes, n_closest);
         __syncthreads();
-        int q0 = 0;
+        int q = 0;
         if (P.msaa > 1) {
             wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, r, &sh);
             __syncthreads();
-            q0 = 1;
+            q = 1;
+            wf_trace_region<false, COUNT>(S, B.rays[1].o_w, B.rays[1].d_ni, mk3(0, 0, 0), B.rays[1].cnt[r], base,
+                                          B.rays[1].hits, nullptr, stk, n_tests, n_nodes, n_closest);
+            __syncthreads();
         }
-        for (int level = 0; level < 5; ++level) {
-            const WfRays in = B.rays[(q0 + level) & 1], out = B.rays[(q0 + level + 1) & 1];
-            const int    n_in = in.cnt[r];
-            if (n_in == 0) break;
-            if (level > 0 || q0 == 1) {
-                wf_trace_region<false, COUNT>(S, in.o_w, in.d_ni, mk3(0, 0, 0), n_in, base, B.hits, nullptr, stk,
-                                       n_tests, n_nodes, n_closest);
+        // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
+        if (B.rays[q].cnt[r] > 0) {
+            wf_shade_region(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh);
+            __syncthreads();
+            for (int level = 0; level < 5; ++level, q ^= 1) {
+                const WfRays in = B.rays[q], out = B.rays[q ^ 1];
+                const int    n_out = out.cnt[r];
+                wf_trace_merged<COUNT>(S, P, B, out, n_out, r, stk, n_tests, n_nodes, n_closest, n_shadow);
+                __syncthreads();
+                wf_resolve_region(S, P, B, in, r);
+                if (n_out == 0) break;
+                __syncthreads(); // resolve still reads the queue the next shade writes its children to
+                wf_shade_region(S, P, B, out, in, r, &sh);
                 __syncthreads();
             }
-            wf_shade_region(S, P, B, in, out, r, &sh);
-            __syncthreads();
-            for (int li = 0; li < P.n_lights; ++li)
-                wf_trace_region<true, COUNT>(S, B.sh_org + (size_t)li * B.cap, nullptr,
-                                      mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
-                                      B.sh_cnt[(size_t)li * B.G + r], base, nullptr,
-                                      B.occl + (size_t)li * B.cap, stk, n_tests, n_nodes, n_shadow);
-            __syncthreads();
-            wf_resolve_region(S, P, B, in, r);
             __syncthreads();
         }
         for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
