@@ -1160,7 +1160,7 @@ static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
 // ---------------------------------------------------------------------------
 // wavefront renderer (rt_wavefront.h)
 // ---------------------------------------------------------------------------
-#define WF_STACK_LDS 16 // traversal stack entries per thread kept in LDS
+#define WF_STACK_LDS 12 // traversal stack entries per thread kept in LDS
 #define WF_WORKSPACE_BUDGET ((size_t)12 << 30) // bytes of queues per scene at most
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1175,7 +1175,7 @@ static int wf_prepare(RtScene* s)
     int         cap = cap_env ? atoi(cap_env) : WF_STACK_LDS;
     cap = std::max(1, std::min(cap, (int)s->d.stack_entries));
     s->d.stk_cap = cap;
-    s->wf_lds = (size_t)cap * WF_BLOCK * sizeof(unsigned short);
+    s->wf_lds = (size_t)cap * WF_BLOCK * WF_STACK_ENTRY_BYTES;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
@@ -1190,8 +1190,10 @@ static int wf_prepare(RtScene* s)
                 (int)s->d.stack_entries, cap, s->wf_lds, per_cu);
     const size_t deep = (size_t)(s->d.stack_entries - cap);
     const size_t blocks = (size_t)std::max(g_trace, std::max(g_any, g_pipe));
-    HIP_TRY(hipMalloc(&s->d_stk_spill, std::max<size_t>(deep * blocks * WF_BLOCK * sizeof(unsigned short), 256)));
-    s->d.stk_spill = (unsigned short*)s->d_stk_spill;
+    const size_t n_deep = std::max<size_t>(deep * blocks * WF_BLOCK, 64);
+    HIP_TRY(hipMalloc(&s->d_stk_spill, n_deep * WF_STACK_ENTRY_BYTES)); // floats first, then the node indices
+    s->d.stk_spill_t = (float*)s->d_stk_spill;
+    s->d.stk_spill = (unsigned short*)((float*)s->d_stk_spill + n_deep);
     s->wf_grid_trace = g_trace, s->wf_grid_any = g_any, s->wf_grid_pipe = g_pipe;
     return RT_OK;
 }

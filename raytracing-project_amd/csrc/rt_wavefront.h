@@ -126,43 +126,56 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int n_
 }
 
 // Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray over the compact node
-// array.  Inner nodes carry no triangles (they were handed down to the leaves).  A stack
-// entry names the inner node whose far child is still to be visited; the far child and
-// its entry t are recomputed from that node when it is popped (same expression as when it
-// was pushed, hence the same value).  The traversal arithmetic (plane distances) is free
+// array.  Inner nodes carry no triangles (they were handed down to the leaves).  The
+// traversal arithmetic (plane distances) is free
 // to use fused multiply-add: it only decides which cells are visited, with a safety
 // margin; which triangle is hit, and where, is decided by tri_test alone.  The result
 // equals the reference's leaf walk (raytracing.cpp:281-351): the smallest t over all
 // triangles, ties to the triangle that walk would have tested last.
-// Per-thread traversal stack of node indices.  Entry e of a thread sits at lds[e * WF_BLOCK]
-// while e < cap, else at spill[(e - cap) * WF_BLOCK].  Rays rarely have more than a dozen
-// far children pending, so a short LDS part serves nearly all pushes and pops while the
-// tree's full depth stays available; LDS per block, and with it the number of resident
-// waves, no longer grows with the depth of the tree.
+// Per-thread traversal stack.  An entry is the far child still to be visited (16-bit node
+// index) and the ray parameter at which the ray enters it.  Entry e of a thread sits at
+// index e * WF_BLOCK of the LDS arrays while e < cap, else at (e - cap) * WF_BLOCK of the
+// spill arrays in HBM.  Rays rarely have more than a dozen far children pending, so a short
+// LDS part serves nearly all pushes and pops while the tree's full depth stays available;
+// LDS per block, and with it the number of resident waves, does not grow with the depth of
+// the tree.
 struct WfStack {
-    unsigned short* lds;
-    unsigned short* spill;
+    unsigned short* lds_node;
+    float*          lds_t;
+    unsigned short* spill_node;
+    float*          spill_t;
     int             cap;
 };
+
+// LDS layout per block: float t[cap][WF_BLOCK], then ushort node[cap][WF_BLOCK]
+#define WF_STACK_ENTRY_BYTES 6
 
 __device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_mem)
 {
     WfStack k;
-    k.lds = (unsigned short*)s_mem + threadIdx.x;
     k.cap = S.stk_cap;
-    k.spill = S.stk_spill + (size_t)blockIdx.x * (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK + threadIdx.x;
+    k.lds_t = (float*)s_mem + threadIdx.x;
+    k.lds_node = (unsigned short*)(s_mem + (size_t)k.cap * WF_BLOCK * sizeof(float)) + threadIdx.x;
+    const size_t deep = (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK;
+    k.spill_t = S.stk_spill_t + (size_t)blockIdx.x * deep + threadIdx.x;
+    k.spill_node = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
     return k;
 }
 
-__device__ __forceinline__ void wf_stk_put(const WfStack& k, int e, int node)
+__device__ __forceinline__ void wf_stk_put(const WfStack& k, int e, int node, float t)
 {
-    if (e < k.cap) k.lds[e * WF_BLOCK] = (unsigned short)node;
-    else k.spill[(size_t)(e - k.cap) * WF_BLOCK] = (unsigned short)node;
+    if (e < k.cap) k.lds_node[e * WF_BLOCK] = (unsigned short)node, k.lds_t[e * WF_BLOCK] = t;
+    else k.spill_node[(size_t)(e - k.cap) * WF_BLOCK] = (unsigned short)node, k.spill_t[(size_t)(e - k.cap) * WF_BLOCK] = t;
 }
 
-__device__ __forceinline__ int wf_stk_get(const WfStack& k, int e)
+__device__ __forceinline__ int wf_stk_node(const WfStack& k, int e)
 {
-    return e < k.cap ? k.lds[e * WF_BLOCK] : k.spill[(size_t)(e - k.cap) * WF_BLOCK];
+    return e < k.cap ? k.lds_node[e * WF_BLOCK] : k.spill_node[(size_t)(e - k.cap) * WF_BLOCK];
+}
+
+__device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
+{
+    return e < k.cap ? k.lds_t[e * WF_BLOCK] : k.spill_t[(size_t)(e - k.cap) * WF_BLOCK];
 }
 
 template <bool ANY, bool COUNT = true>
@@ -198,7 +211,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             } else if (tplane < tmin_e) {
                 node = left + (below ? 1 : 0);
             } else {
-                wf_stk_put(stk, sp, node);
+                wf_stk_put(stk, sp, left + (below ? 1 : 0), tplane);
                 ++sp;
                 node = near;
                 tmax_e = tplane * (1.0f + RT_TRAV_EPS);
@@ -245,23 +258,11 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         bool found = false;
         while (sp > 0) {
             --sp;
-            const uint2    pn = S.knodes[wf_stk_get(stk, sp)];
-            const unsigned axis = pn.y >> 30;
-            const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
-            const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
-            const float    et = __builtin_fmaf(__uint_as_float(pn.x), ia, -oi);
+            const float et = wf_stk_t(stk, sp);
             if (!ANY && et * (1.0f - RT_TRAV_EPS) > minT) continue;
-            const bool below = (et > 0.0f) == (ia > 0.0f);
-            node = (int)(pn.y & 0x3fffffffu) + (below ? 1 : 0);
+            node = wf_stk_node(stk, sp);
             tmin_e = et * (1.0f - RT_TRAV_EPS);
-            tmax_e = RT_FLT_MAX;
-            if (sp > 0) {
-                const uint2    qn = S.knodes[wf_stk_get(stk, sp - 1)];
-                const unsigned qa = qn.y >> 30;
-                const float    qi = qa == 0 ? ix : (qa == 1 ? iy : iz);
-                const float    qo = qa == 0 ? oix : (qa == 1 ? oiy : oiz);
-                tmax_e = __builtin_fmaf(__uint_as_float(qn.x), qi, -qo) * (1.0f + RT_TRAV_EPS);
-            }
+            tmax_e = sp > 0 ? wf_stk_t(stk, sp - 1) * (1.0f + RT_TRAV_EPS) : RT_FLT_MAX;
             found = true;
             break;
         }
