@@ -89,10 +89,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    # RT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
+    # share the visible GPUs and the tile payloads are gathered through host memory.  It checks
+    # the partition / pack / gather / unpack path, not RCCL, and its timings mean nothing.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("raytracing-project_amd")
     capi, host = pkg.capi, pkg.host
@@ -125,7 +134,11 @@ def main():
             capi.check(L.rt_pack_tiles_device(local, C.byref(p), C.c_void_p(rgb.data_ptr()),
                                               C.c_void_p(depth.data_ptr()),
                                               C.c_void_p(payload.data_ptr()), C.c_void_p(stream)))
-            pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack)
+            if backend == "gloo":
+                pkg.distributed.gather_frame(payload.cpu(), W, H, TILE, TILE, rank, world, dist,
+                                             lambda src, buf: unpack(src, buf.to(dev)))
+            else:
+                pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack)
         if rank == 0:
             # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
             for _ in range(2):
@@ -147,7 +160,12 @@ def main():
     my = torch.tensor([float(my_rays), float(st.tri_tests), float(st.node_visits)],
                       dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(my)
+        if backend == "gloo":
+            my_c = my.cpu()
+            dist.all_reduce(my_c)
+            my = my_c
+        else:
+            dist.all_reduce(my)
     rays_per_frame, tests_per_frame, nodes_per_frame = (float(x) for x in my.tolist())
 
     for _ in range(args.warmup):
@@ -163,9 +181,23 @@ def main():
     gs.set_timing(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
+        if backend == "gloo":
+            el = el.cpu()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    if rank == 0 and world > 1 and os.environ.get("RT_BENCH_CHECK") == "1":
+        # rehearsal check: the gathered frame equals the frame one GPU renders alone
+        p1 = capi.default_params(W, H, MSAA)
+        rgb1 = torch.zeros_like(rgb)
+        depth1 = torch.zeros_like(depth)
+        gs.render_device(corners, lights, p1, rgb1.data_ptr(), depth1.data_ptr(), 0, stream, False)
+        torch.cuda.synchronize()
+        same = bool((rgb1 == rgb).all().item())
+        print(f"partition check: gathered frame {'equals' if same else 'DIFFERS FROM'} the single-GPU frame",
+              file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(2)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = rays_per_frame * args.steps / elapsed / 1e6

@@ -147,6 +147,11 @@ struct HitRec {
 // only by tests that are hits or lie within 1e-5 of an edge.  Whatever is not certain
 // falls through to the full evaluation, so the outcome is the reference's in every case
 // (finite inputs assumed: a NaN numerator would slip through the reference's comparisons).
+// Measured on final.obj at 4K MSAA4: 1.44 G tests reach the first numerator pair, 55 % go on
+// to the second, 21 % to the third, 10 % to the divisions; per wave (a stage runs when any
+// lane needs it) the figures are 60 % / 26 % / 13 %.  Testing two triangles per call with
+// packed FP32 arithmetic was tried and is slower (13.6-15.6 vs 12.7 ms per frame): the pair
+// needs twice the registers and survives a stage whenever either triangle does.
 __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, f3 o,
                                          f3 d, float minT, float& a, float& b, float& t)
 {

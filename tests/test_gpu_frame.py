@@ -275,3 +275,23 @@ def test_render_paths_agree(P, oracle, monkeypatch):
     d = np.abs(oracle.to_bytes(a[0]).astype(int) - oracle.to_bytes(c[0]).astype(int))
     assert d.max() <= 1
     assert a[3].rays_closest == c[3].rays_closest
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py as two ranks sharing this GPU, payloads gathered through host memory (gloo):
+    the tile partition, pack, gather and unpack path of the N > 1 bench, end to end; the
+    gathered frame must equal the frame one GPU renders alone (bench.py checks it itself)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_CHECK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gathered frame equals the single-GPU frame" in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["roofline"]["kernel"] == "k_wf_pipeline" and "cpu_baseline" not in out
