@@ -711,7 +711,10 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         // heuristic over the triangles' bounds inside the cell).  The planes of the
         // reference's tree stay; this only adds levels below its leaves, and the
         // closest hit over all triangles does not depend on how they are grouped.
-        // RT_KD_REFINE=0 switches it off.
+        // RT_KD_REFINE=0 switches it off.  Tried and not kept: candidate planes and counts from
+        // the triangles clipped to the cell ("perfect splits": more empty-space cuts, the node
+        // budget runs out, 12.3 vs 12.0 ms per 4K frame), and building the whole tree this way
+        // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms).
         const char* rf_env = getenv("RT_KD_REFINE");
         if (!(rf_env && rf_env[0] == '0')) {
             const char*  lt_env = getenv("RT_KD_LEAF");
