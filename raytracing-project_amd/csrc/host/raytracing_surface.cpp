@@ -35,6 +35,7 @@ bool fail(const std::string& what)
 } // namespace
 
 const std::string& lastError() { return g_error; }
+void               setLastError(const std::string& message) { g_error = message; }
 RtScene*           gpuScene() { return g_scene; }
 
 // Fills an RtSceneDesc that points into mesh/tree (valid while they live).

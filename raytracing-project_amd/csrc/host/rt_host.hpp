@@ -56,6 +56,10 @@ struct KdTree {
 // KDtree.cpp:15
 void buildKDtree(const Mesh& mesh, KdTree& tree);
 
+// PNG -> RGBA8 as corona::OpenImage(path, PF_R8G8B8A8) delivers it (mesh.h:117-135).
+bool decodePng(const uint8_t* data, size_t size, Texture& out, std::string& err);
+bool readPng(const std::string& path, Texture& out, std::string& err);
+
 // camera.sav of main.cpp:270-307: 16 floats of the column-major modelview,
 // the number of lights, one light per line.
 bool readCameraSav(const char* path, double modelview[16], std::vector<Vec3Df>& lights);
@@ -95,6 +99,7 @@ extern RtParams            MySettings; // settings.h + config.h values
 bool init(const char* obj_path, int device = 0, bool loadTextures = true);
 void shutdown();
 const std::string& lastError();
+void               setLastError(const std::string& message);
 RtScene*           gpuScene();
 // raytracing.h:33
 Vec3Df performRayTracing(const Vec3Df& origin, const Vec3Df& dest, int k, float prev_Ni, float& minT);

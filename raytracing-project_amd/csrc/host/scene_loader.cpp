@@ -9,7 +9,8 @@
 //   * material 0 is a built-in grey one (mesh.cpp:110-119);
 //   * polygons are fanned (0, i+1, i+2) (mesh.cpp:303-325);
 //   * lines are read through a 256-byte buffer (mesh.cpp:26,153).
-// Textures are read from "<name>.rtex" files next to the scene (pre-decoded
+// Textures are read from the PNG the material names (png_decoder.cpp) or, when that file
+// is not there, from a "<name>.rtex" file next to the scene (pre-decoded
 // RGBA8, zlib-compressed; see tools/decode_textures.py); '\' in a map_Kd path
 // becomes '/', relative paths resolve against the .obj directory and absolute
 // paths are not found, as on any machine but the scene authors'.
@@ -251,13 +252,15 @@ bool Mesh::loadMesh(const char* filename, bool /*randomizeTriangulation*/, bool 
             const bool absolute =
                 !rel.empty() && (rel[0] == '/' || (rel.size() > 1 && isalpha((unsigned char)rel[0]) && rel[1] == ':'));
             if (!rel.empty() && !absolute) {
-                const std::string path = dir + rel + ".rtex";
+                // the image file itself if it is there (mesh.h:120), else its pre-decoded copy
+                const std::string png = dir + rel, path = dir + rel + ".rtex";
                 int               found = -1;
                 for (size_t i = 0; i < textures.size(); ++i)
-                    if (textures[i].path == path) found = (int)i;
+                    if (textures[i].path == path || textures[i].path == png) found = (int)i;
                 if (found < 0) {
-                    Texture t;
-                    if (readRtex(path, t)) {
+                    Texture     t;
+                    std::string why;
+                    if (readPng(png, t, why) || readRtex(path, t)) {
                         textures.push_back(std::move(t));
                         found = (int)textures.size() - 1;
                     } else {

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librt_host.so")
 EXPORTS = ["rth_scene_load", "rth_scene_free", "rth_scene_desc", "rth_tree_depth",
            "rth_material_name", "rth_read_camera_sav", "rth_camera_corners", "rth_write_ppm",
            "rth_write_bmp", "rth_write_depth_bmp", "rth_write_blurred_bmp", "rth_render_to_files",
-           "rth_last_error"]
+           "rth_last_error", "rth_decode_png"]
 
 _lib = None
 
@@ -46,6 +46,7 @@ def lib():
     L.rth_render_to_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                       C.c_int, C.POINTER(capi.RtStats)]
     L.rth_last_error.restype = C.c_char_p
+    L.rth_decode_png.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), P, C.c_size_t]
     _lib = L
     return L
 
@@ -123,6 +124,17 @@ class GpuScene(capi.Scene):
         h = C.c_void_p()
         capi.check(capi.lib().rt_scene_create(C.byref(host_scene.desc), device, C.byref(h)))
         self.h = h
+
+
+def decode_png(data):
+    """PNG bytes -> (H, W, 4) uint8 RGBA, the host library's decoder (png_decoder.cpp)."""
+    w, h = C.c_int(0), C.c_int(0)
+    if lib().rth_decode_png(data, len(data), C.byref(w), C.byref(h), None, 0) != 0:
+        raise ValueError(lib().rth_last_error().decode(errors="replace"))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    if lib().rth_decode_png(data, len(data), None, None, out.ctypes.data, out.size) != 0:
+        raise ValueError(lib().rth_last_error().decode(errors="replace"))
+    return out
 
 
 def read_camera_sav(path):

@@ -167,3 +167,171 @@ def test_tile_pack_unpack_roundtrip(P):
     for r in range(3):
         P.tiles.unpack(P.tiles.pack(rgb, depth, 16, 8, r, 3), rgb2, depth2, 16, 8, r, 3)
     assert np.array_equal(rgb, rgb2) and np.array_equal(depth, depth2)
+
+
+# ---- PNG decoder (the reference gets RGBA8 from the Corona library, mesh.h:117-135) ----
+def _png_chunk(kind, body):
+    import struct
+    import zlib
+    return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+
+
+def _png_encode(img, depth, ctype, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """Small PNG writer for the tests.  img: (H, W, channels) array of samples (< 2**depth)."""
+    import struct
+    import zlib
+    H, W, ch = img.shape
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def pack_line(row):                      # row: (w, ch) samples -> bytes
+        flat = row.reshape(-1).astype(np.uint32)
+        if depth == 8:
+            return flat.astype(np.uint8).tobytes()
+        if depth == 16:
+            return flat.astype(">u2").tobytes()
+        bitstr = "".join(format(int(v), f"0{depth}b") for v in flat)
+        bitstr += "0" * (-len(bitstr) % 8)
+        return bytes(int(bitstr[i:i + 8], 2) for i in range(0, len(bitstr), 8))
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def filt(kind, cur, prev):
+        out = bytearray(len(cur))
+        for i, x in enumerate(cur):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i] if prev is not None else 0
+            c = prev[i - bpp] if prev is not None and i >= bpp else 0
+            pred = (0, a, b, (a + b) >> 1, paeth(a, b, c))[kind]
+            out[i] = (x - pred) & 0xff
+        return bytes(out)
+
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] \
+        if interlace else [(0, 0, 1, 1)]
+    raw = b""
+    k = 0
+    for x0, y0, dx, dy in passes:
+        sub = img[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for row in sub:
+            cur = pack_line(row)
+            kind = filters[k % len(filters)]
+            k += 1
+            raw += bytes([kind]) + filt(kind, cur, prev)
+            prev = cur
+    data = b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, int(interlace)))
+    if palette is not None:
+        data += _png_chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    if trns is not None:
+        data += _png_chunk(b"tRNS", bytes(trns))
+    data += _png_chunk(b"tEXt", b"Comment\x00ancillary chunks are skipped")
+    z = zlib.compress(raw, 6)
+    half = len(z) // 2                        # two IDAT chunks: the stream is their concatenation
+    data += _png_chunk(b"IDAT", z[:half]) + _png_chunk(b"IDAT", z[half:]) + _png_chunk(b"IEND", b"")
+    return data
+
+
+def _expect_rgba(img, depth, ctype, palette=None, trns=None):
+    H, W, ch = img.shape
+    maxv = (1 << depth) - 1
+
+    def to8(v):
+        v = v.astype(np.uint32)
+        return (v if depth == 8 else (v >> 8) if depth == 16 else (v * 255 + maxv // 2) // maxv).astype(np.uint8)
+    out = np.zeros((H, W, 4), np.uint8)
+    out[..., 3] = 255
+    if ctype == 0:
+        out[..., :3] = to8(img[..., 0])[..., None]
+        if trns is not None:
+            out[..., 3] = np.where(img[..., 0] == int.from_bytes(trns[:2], "big"), 0, 255)
+    elif ctype == 2:
+        out[..., :3] = to8(img)
+        if trns is not None:
+            key = [int.from_bytes(trns[2 * c:2 * c + 2], "big") for c in range(3)]
+            out[..., 3] = np.where((img == key).all(-1), 0, 255)
+    elif ctype == 3:
+        pal = np.asarray(palette, np.uint8)
+        out[..., :3] = pal[img[..., 0]]
+        if trns is not None:
+            a = np.full(len(pal), 255, np.uint8)
+            a[:len(trns)] = np.frombuffer(bytes(trns), np.uint8)
+            out[..., 3] = a[img[..., 0]]
+    elif ctype == 4:
+        out[..., :3] = to8(img[..., 0])[..., None]
+        out[..., 3] = to8(img[..., 1])
+    else:
+        out[...] = to8(img)
+    return out
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("ctype,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2),
+                                         (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)])
+def test_png_decoder_all_formats(P, ctype, depth, interlace):
+    rng = np.random.default_rng(100 * ctype + depth + int(interlace))
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    for W, H in ((1, 1), (5, 3), (13, 17), (32, 9)):
+        palette = trns = None
+        hi = 1 << depth
+        if ctype == 3:
+            n_pal = min(hi, 200)
+            palette = rng.integers(0, 256, (n_pal, 3))
+            trns = bytes(rng.integers(0, 256, n_pal // 2).astype(np.uint8)) if depth >= 2 else None
+            hi = n_pal
+        img = rng.integers(0, hi, (H, W, ch))
+        if ctype == 0 and depth == 8:
+            trns = bytes([0, int(img[0, 0, 0])])
+        if ctype == 2 and depth == 8:
+            trns = b"".join(int(v).to_bytes(2, "big") for v in img[H - 1, W - 1])
+        png = _png_encode(img, depth, ctype, interlace, palette, trns)
+        got = P.host.decode_png(png)
+        assert np.array_equal(got, _expect_rgba(img, depth, ctype, palette, trns)), (ctype, depth, W, H)
+
+
+def test_png_decoder_matches_pillow(P):
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(9)
+    arr = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    arr[5:20, 5:30] = arr[5, 5]                  # flat areas: the encoder's adaptive filters vary
+    for mode in ("RGBA", "RGB", "L", "LA", "P"):
+        im = PIL.fromarray(arr, "RGBA").convert(mode)
+        buf = io.BytesIO()
+        im.save(buf, "PNG", optimize=(mode != "P"))
+        want = np.asarray(PIL.open(io.BytesIO(buf.getvalue())).convert("RGBA"))
+        assert np.array_equal(P.host.decode_png(buf.getvalue()), want), mode
+
+
+def test_png_decoder_rejects_damage(P):
+    img = np.random.default_rng(2).integers(0, 256, (6, 7, 3))
+    png = _png_encode(img, 8, 2)
+    for bad in (png[:20], b"JUNK" + png[4:], png[:40] + bytes([png[40] ^ 1]) + png[41:], png[:-12]):
+        with pytest.raises(ValueError):
+            P.host.decode_png(bad)
+
+
+def test_png_decoder_reproduces_shipped_textures(P):
+    """The scenes' pre-decoded textures (made with Pillow) against this decoder on the
+    original PNG files, where the reference checkout is present (it is not on the GPU box)."""
+    import struct
+    import zlib
+    src = "/root/reference/textures"
+    if not os.path.isdir(src):
+        pytest.skip("reference checkout not present")
+    n = 0
+    tdir = os.path.join(SCENES, "textures")
+    for name in sorted(os.listdir(tdir)):
+        if not name.endswith(".rtex") or not os.path.exists(os.path.join(src, name[:-5])):
+            continue
+        blob = open(os.path.join(tdir, name), "rb").read()
+        w, h, zl = struct.unpack("<III", blob[4:16])
+        want = np.frombuffer(zlib.decompress(blob[16:16 + zl]), np.uint8).reshape(h, w, 4)
+        got = P.host.decode_png(open(os.path.join(src, name[:-5]), "rb").read())
+        assert np.array_equal(got, want), name
+        n += 1
+    assert n >= 7
