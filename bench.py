@@ -113,33 +113,49 @@ def main():
     corners = host.camera_corners(m, W, H)
     p = capi.default_params(W, H, MSAA)
     p.tile_w = p.tile_h = TILE
-    p.rank, p.world = rank, world
 
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     depth = torch.zeros((H, W), dtype=torch.float32, device=dev)
     blurred = torch.zeros((H - 12, W - 12, 3), dtype=torch.float32, device=dev)
-    n_slots = capi.lib().rt_tile_pixels(C.byref(p), rank)
-    payload = torch.zeros((n_slots, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     L = capi.lib()
+    PER_RANK = 16   # shares per GPU in the deal; rank 0 may own fewer (it also runs the post-process)
+    state = {}
+
+    def set_deal(first_rank_shares):
+        """Tiles are dealt over n_shares = first_rank_shares + 16 (N - 1) shares; rank r renders
+        `span` consecutive ones (RtParams.rank / world / rank_span)."""
+        n_shares, deal = pkg.tiles.shares(world, first_rank_shares / PER_RANK, PER_RANK)
+        p.rank, p.rank_span = deal[rank]
+        p.world = n_shares
+        n_slots = L.rt_tile_pixels(C.byref(p), p.rank)
+        state.update(deal=(n_shares, deal), first_rank_shares=deal[0][1],
+                     payload=torch.zeros((max(n_slots, 1), 4), dtype=torch.float32, device=dev)[:n_slots])
+
+    set_deal(PER_RANK)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def unpack(src, buf):
-        capi.check(L.rt_unpack_tiles_device(local, C.byref(p), src, C.c_void_p(buf.data_ptr()),
+        ps = capi.RtParams.from_buffer_copy(p)      # the source rank's shares
+        ps.rank, ps.rank_span = state["deal"][1][src]
+        capi.check(L.rt_unpack_tiles_device(local, C.byref(ps), ps.rank, C.c_void_p(buf.data_ptr()),
                                             C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
                                             C.c_void_p(stream)))
 
     def frame(stats=False):
         st = gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, stream, stats)
         if world > 1:
+            payload = state["payload"]
             capi.check(L.rt_pack_tiles_device(local, C.byref(p), C.c_void_p(rgb.data_ptr()),
                                               C.c_void_p(depth.data_ptr()),
                                               C.c_void_p(payload.data_ptr()), C.c_void_p(stream)))
             if backend == "gloo":
                 pkg.distributed.gather_frame(payload.cpu(), W, H, TILE, TILE, rank, world, dist,
-                                             lambda src, buf: unpack(src, buf.to(dev)))
+                                             lambda src, buf: unpack(src, buf.to(dev)), state["deal"])
             else:
-                pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack)
+                pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack, state["deal"])
         if rank == 0:
+            ev[0].record()
             # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
             for _ in range(2):
                 capi.check(L.rt_normalize_depth_device(local, W * H, p.focusDepth,
@@ -147,12 +163,57 @@ def main():
             capi.check(L.rt_dof_blur_device(local, W, H, p.depthPower, C.c_void_p(rgb.data_ptr()),
                                             C.c_void_p(depth.data_ptr()),
                                             C.c_void_p(blurred.data_ptr()), C.c_void_p(stream)))
+            ev[1].record()
         return st
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def bcast_int(v):
+        t = torch.tensor([int(v)], dtype=torch.int64, device="cpu" if backend == "gloo" else dev)
+        dist.broadcast(t, src=0)
+        return int(t.item())
+
+    def timed_frames(n):
+        """(this rank's render ms, rank 0's post-process ms) averaged over n frames."""
+        gs.set_timing(True)
+        post = 0.0
+        for _ in range(n):
+            frame()
+            torch.cuda.synchronize()
+            if rank == 0:
+                post += ev[0].elapsed_time(ev[1]) / n
+        kt_ = gs.collect_timing()
+        gs.set_timing(False)
+        return kt_.frame_ms / max(kt_.frames, 1), post
+
+    # Static load balance, settled before the timed region: rank 0 also unpacks the gathered
+    # tiles and runs the depth passes and the blur, so it is dealt fewer tiles.  With a render
+    # time of A * (fraction of the frame) + tail per rank, the frame is balanced when rank 0's
+    # fraction is f0 = (1 - (N - 1) * t_post / A) / N; A comes from rank 0's render time under
+    # two deals (equal shares, half shares).
+    calib = None
+    if world > 1 and os.environ.get("RT_BENCH_EVEN") != "1":
+        frame()                                        # first-touch allocations
+        t_eq, t_post = timed_frames(2)
+        f_eq = PER_RANK / state["deal"][0]
+        set_deal(PER_RANK // 2)
+        frame()
+        t_half, _ = timed_frames(2)
+        f_half = state["first_rank_shares"] / state["deal"][0]
+        shares0 = PER_RANK
+        if rank == 0:
+            slope = (t_eq - t_half) / (f_eq - f_half)  # ms per unit fraction of the frame
+            if slope > 0:
+                f0 = (1.0 - (world - 1) * (t_post + 0.1) / slope) / world   # + 0.1 ms for the unpack kernels
+                f0 = min(max(f0, 0.2 / world), 1.0 / world)
+                shares0 = int(round(PER_RANK * (world - 1) * f0 / (1.0 - f0)))
+            calib = {"render_ms_equal": round(t_eq, 3), "render_ms_half": round(t_half, 3),
+                     "post_ms": round(t_post, 3)}
+        shares0 = bcast_int(min(max(shares0, 1), PER_RANK))
+        set_deal(shares0)
 
     # one counted frame: rays this rank traces per frame (deterministic)
     st = frame(stats=True)
@@ -210,8 +271,10 @@ def main():
                     "published camera exists, this one is fixed in the repo)",
             "config": {"workload": f"{SCENE}.obj {W}x{H} MSAA{MSAA} + DoF, {len(lights)} lights, "
                                    "reflection/refraction depth 5",
-                       "partition": f"{TILE}x{TILE} tiles round-robin over {world} GPU(s), "
-                                    "RCCL gather to rank 0" if world > 1 else f"{TILE}x{TILE} tiles, 1 GPU",
+                       "partition": (f"{TILE}x{TILE} tiles dealt over {state['deal'][0]} shares: rank 0 renders "
+                                     f"{state['first_rank_shares']}, every other rank {PER_RANK} (rank 0 also runs the "
+                                     "post-process); RCCL gather to rank 0") if world > 1
+                       else f"{TILE}x{TILE} tiles, 1 GPU",
                        "rays_per_frame": int(rays_per_frame),
                        "tri_tests_per_ray": round(tests_per_frame / rays_per_frame, 2),
                        "nodes_per_ray": round(nodes_per_frame / rays_per_frame, 2)},
@@ -234,7 +297,9 @@ def main():
                 # shadowMax (raytracing.cpp:127-143).  flops_needed leaves both out; the headline
                 # figure uses it, the figure for the full walk is reported next to it.
                 f_needed = fc.get("flops_needed", fc["flops_frame"])
-                f_kernel = f_needed / world
+                # rank 0's launch covers its own fraction of the frame (the HIP events are rank 0's)
+                frac0 = state["first_rank_shares"] / state["deal"][0] if world > 1 else 1.0
+                f_kernel = f_needed * frac0
                 kern_ms = kt.frame_ms / kt.frames
                 ach = f_kernel / (kern_ms * 1e-3) / 1e12
                 traffic = None
@@ -250,7 +315,7 @@ def main():
                         "launches_per_frame": round(kt.frames / args.steps, 2),
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "frac_reference_walk": round(
-                            fc["flops_frame"] / world / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                            fc["flops_frame"] * frac0 / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                         "note": "no MFMA on this path: the bound is the FP32 vector peak (= the f32 MFMA "
                                 "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk "
                                 "(T = %d ray/triangle tests, S = %d leaf steps per frame)"
@@ -263,6 +328,8 @@ def main():
                                 "achieved_gbs": round(hbm_bytes / (ms * 1e-3) / 1e9, 2),
                                 "peak_gbs": HBM_PEAK_GBS,
                                 "frac": round(hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+        if calib:
+            out["config"]["load_balance_calibration"] = calib
         out["roofline"] = roof
         out["kernel_ms"] = {"k_wf_pipeline": round(kt.frame_ms / max(kt.frames, 1), 3),
                             "dof_and_gather": round(ms - kt.frame_ms / max(kt.frames, 1), 3)}

@@ -97,11 +97,17 @@ typedef struct RtParams {
     float   depthPower;        /* settings.h:16 */
     float   backgroundColor[3]; /* settings.h:18 */
     float   focusDepth;        /* raytracing.cpp:17 */
-    /* Tiles of tile_w x tile_h pixels (multiples of 8) are dealt round-robin:
-     * this call renders tiles t with t % world == rank.  tile_w == 0 means
-     * the whole frame (rank 0 of 1). */
+    /* Tiles of tile_w x tile_h pixels (multiples of 8) are dealt round-robin
+     * over `world` shares: this call renders the tiles t whose share t % world
+     * lies in [rank, rank + rank_span).  rank_span <= 0 means 1, i.e. the plain
+     * round-robin "t % world == rank"; a caller that wants one GPU to carry
+     * less of the frame than the others (it also runs the post-process, say)
+     * uses more shares than GPUs and hands them out unevenly.  tile_w == 0
+     * means the whole frame (rank 0 of 1). */
     int32_t tile_w, tile_h;
     int32_t rank, world;
+    int32_t rank_span;
+    int32_t reserved;
 } RtParams;
 
 typedef struct RtStats {
@@ -205,7 +211,9 @@ int rt_dof_blur_device(int device, int32_t width, int32_t height, float depth_po
 int rt_quantize(int device, int64_t n, const float *v, uint8_t *out);
 
 /* Screen-space partition helpers.  They replace the row bands of
- * main.cpp:329-339 when a frame is shared by `world` GPUs.
+ * main.cpp:329-339 when a frame is shared by several GPUs.  Where a rank is
+ * passed explicitly it replaces params->rank; params->rank_span is the span of
+ * THAT rank (the caller sets it to the source's span before unpacking).
  * rt_tile_pixels: number of pixel slots (whole tiles) rank owns.
  * rt_pack_tiles_device: copy the rank's tiles of the frame buffers into a
  *   payload of rt_tile_pixels * 4 floats (r g b depth per pixel slot).

@@ -1020,14 +1020,17 @@ static int set_partition(const RtParams* p, int rank, DParams* d)
     }
     if (tw < 8 || th < 8 || (tw & 7) || (th & 7) || tw > 1024 || th > 1024)
         return fail(RT_ERR_INVALID, "tile size %dx%d must be multiples of 8 in 8..1024", tw, th);
-    if (world < 1 || rank < 0 || rank >= world)
-        return fail(RT_ERR_INVALID, "rank %d / world %d invalid", rank, world);
-    d->tile_w = tw, d->tile_h = th, d->rank = rank, d->world = world;
+    int span = p->rank_span <= 0 ? 1 : p->rank_span;
+    if (p->tile_w == 0 && p->tile_h == 0) span = 1;
+    if (world < 1 || rank < 0 || rank >= world || span > world - rank)
+        return fail(RT_ERR_INVALID, "rank %d (span %d) / world %d invalid", rank, span, world);
+    d->tile_w = tw, d->tile_h = th, d->rank = rank, d->world = world, d->span = span;
     d->tiles_x = (p->width + tw - 1) / tw;
     d->tiles_y = (p->height + th - 1) / th;
+    // tiles t with t % world in [rank, rank + span): span per full round, the head of the last
     const long long n_tiles = (long long)d->tiles_x * d->tiles_y;
-    d->n_my_tiles = (int)((n_tiles - rank + world - 1) / world);
-    if (d->n_my_tiles < 0) d->n_my_tiles = 0;
+    const long long rem = n_tiles % world;
+    d->n_my_tiles = (int)((n_tiles / world) * span + std::max<long long>(0, std::min<long long>(rem - rank, span)));
     return RT_OK;
 }
 

@@ -66,7 +66,7 @@ struct DParams {
     float   bg[3];
     float   pad1;
     int32_t tile_w, tile_h, rank, world;
-    int32_t tiles_x, tiles_y, n_my_tiles, pad2;
+    int32_t tiles_x, tiles_y, n_my_tiles, span; // span: consecutive shares this call covers, from `rank`
     float   cam[24];
     float   lights[3 * RT_MAX_LIGHTS_DEV];
 };
@@ -465,7 +465,8 @@ __device__ __forceinline__ void pixel_ray(const DParams& P, double x, double y, 
     d = (d00 * xs + d10 * xs1) * ys + (d01 * xs + d11 * xs1) * ys1;
 }
 
-// Pixel slot -> pixel.  Slots enumerate this rank's tiles in order; inside a
+// Pixel slot -> pixel.  Slots enumerate this rank's tiles in order (the tiles of its
+// shares rank .. rank + span - 1, round after round); inside a
 // tile pixels go by 8x8 blocks so that the 64 lanes of a wave cover a compact
 // screen area.
 __device__ __forceinline__ bool slot_to_pixel(const DParams& P, long long slot, int& x, int& y)
@@ -474,7 +475,7 @@ __device__ __forceinline__ bool slot_to_pixel(const DParams& P, long long slot, 
     const long long lt = slot / tile_px;
     const int       within = (int)(slot - lt * tile_px);
     if (lt >= P.n_my_tiles) return false;
-    const long long gt = lt * P.world + P.rank;
+    const long long gt = (lt / P.span) * P.world + P.rank + lt % P.span;
     const int       tx = (int)(gt % P.tiles_x), ty = (int)(gt / P.tiles_x);
     const int       blk = within >> 6, in = within & 63;
     const int       bpr = P.tile_w >> 3; // 8x8 blocks per tile row

@@ -11,16 +11,19 @@ import numpy as np
 from . import tiles
 
 
-def gather_frame(payload, W, H, tile_w, tile_h, rank, world, dist=None, unpack=None):
+def gather_frame(payload, W, H, tile_w, tile_h, rank, world, dist=None, unpack=None, deal=None):
     """Gathers every rank's (n_slots, 4) payload tensor on rank 0 and rebuilds the
     frame there.  `payload` is a torch tensor on the device the process group
     communicates on.  `unpack(src_rank, payload_tensor)` writes one rank's tiles
     into the caller's frame buffers (a GPU kernel on the GPU box, numpy in the
-    CPU tests).  Ranks other than 0 return after the gather."""
+    CPU tests).  Ranks other than 0 return after the gather.  `deal` = (n_shares, [(first
+    share, span) per rank]) for an uneven deal (tiles.shares); None = one share per rank."""
     import torch
 
     tile_px = tile_w * tile_h
-    max_slots = max(tiles.n_my_tiles(W, H, tile_w, tile_h, r, world) for r in range(world)) * tile_px
+    if deal is None:
+        deal = (world, [(r, 1) for r in range(world)])
+    max_slots = max(tiles.n_my_tiles(W, H, tile_w, tile_h, f, deal[0], s) for f, s in deal[1]) * tile_px
     if world == 1:
         unpack(0, payload)
         return

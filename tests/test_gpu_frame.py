@@ -120,6 +120,36 @@ def test_partitioned_render_equals_whole_frame(P, name, msaa):
     assert rays == whole[3].rays_closest + whole[3].rays_shadow
 
 
+def test_uneven_deal_render_pack_unpack(P):
+    """Three GPUs' worth of an uneven deal (rank_span), rendered one after the other, packed
+    and unpacked through the tile payloads: the frame equals the one-piece render."""
+    import torch
+    hs, gs, m, lights = _host_gpu(P, "final")
+    W, H, msaa = 200, 136, 4
+    corners = P.host.camera_corners(m, W, H)
+    whole = gs.render(corners, lights, P.capi.default_params(W, H, msaa))
+    world, deal = P.tiles.shares(3, 0.375, per_rank=8)
+    assert deal[0] == (0, 3) and world == 19
+    out_rgb = torch.zeros((H, W, 3), device="cuda")
+    out_depth = torch.zeros((H, W), device="cuda")
+    L = P.capi.lib()
+    for first, span in deal:
+        p = P.capi.default_params(W, H, msaa)
+        p.tile_w, p.tile_h, p.rank, p.world, p.rank_span = 16, 8, first, world, span
+        rgb = torch.zeros((H, W, 3), device="cuda")
+        depth = torch.zeros((H, W), device="cuda")
+        gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0)
+        n = L.rt_tile_pixels(C.byref(p), first)
+        assert n == P.tiles.n_my_tiles(W, H, 16, 8, first, world, span) * 128
+        payload = torch.zeros((n, 4), device="cuda")
+        P.capi.check(L.rt_pack_tiles_device(0, C.byref(p), C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                            C.c_void_p(payload.data_ptr()), None))
+        P.capi.check(L.rt_unpack_tiles_device(0, C.byref(p), first, C.c_void_p(payload.data_ptr()),
+                                              C.c_void_p(out_rgb.data_ptr()), C.c_void_p(out_depth.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out_rgb.cpu().numpy(), whole[0]) and np.array_equal(out_depth.cpu().numpy(), whole[1])
+
+
 def test_r_path_files_match_oracle_writers(P, oracle, tmp_path):
     """rt_render's path: init() + camera.sav + doDaRayTracingShizz -> four files."""
     name, W, H, msaa = "final", 160, 100, 4

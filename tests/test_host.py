@@ -119,7 +119,7 @@ def test_library_exports_every_declared_symbol(P):
 def test_struct_sizes_match_header(P):
     assert C.sizeof(P.capi.RtMaterial) == 64
     assert C.sizeof(P.capi.RtKdNode) == 40
-    assert C.sizeof(P.capi.RtParams) == 60
+    assert C.sizeof(P.capi.RtParams) == 68
     assert C.sizeof(P.capi.RtStats) == 48
 
 
@@ -156,6 +156,26 @@ def test_tile_partition_covers_every_pixel_once(P, W, H, tw, th, world):
             assert x[:64].max() - x[:64].min() == 7 and y[:64].max() - y[:64].min() == 7
     assert (seen == 1).all()
     p.tile_w = 12
+    assert P.capi.lib().rt_tile_pixels(C.byref(p), 0) == -1
+
+
+@pytest.mark.parametrize("W,H,n_ranks,w0", [(64, 48, 2, 0.5), (100, 70, 3, 0.25), (3840, 2160, 8, 0.4),
+                                              (200, 40, 4, 0.0), (96, 96, 2, 1.0)])
+def test_uneven_deal_covers_every_pixel_once(P, W, H, n_ranks, w0):
+    """rank_span: the first rank owns fewer shares than the others."""
+    tw = th = 16
+    world, deal = P.tiles.shares(n_ranks, w0, per_rank=8)
+    assert sum(s for _, s in deal) == world and deal[0][1] == max(1, round(w0 * 8))
+    seen = np.zeros((H, W), np.int32)
+    p = P.capi.default_params(W, H)
+    p.tile_w, p.tile_h, p.world = tw, th, world
+    for first, span in deal:
+        p.rank_span = span
+        x, y, ok = P.tiles.slot_pixels(W, H, tw, th, first, world, span)
+        assert P.capi.lib().rt_tile_pixels(C.byref(p), first) == len(x)
+        np.add.at(seen, (y[ok], x[ok]), 1)
+    assert (seen == 1).all()
+    p.rank_span = world + 1                   # more shares than there are
     assert P.capi.lib().rt_tile_pixels(C.byref(p), 0) == -1
 
 
