@@ -131,6 +131,27 @@ RayTracer::RayTracer(const double modelview[16], int width, int height) : result
     cameraCorners(modelview, width, height, corners);
 }
 
+bool RayTracer::setFocusAtPixel(double x, double y)
+{
+    const int    W = result.width, H = result.height;
+    const double xscale = 1.0 - x / (double)(W - 1), yscale = 1.0 - y / (double)(H - 1);
+    const float  xs = (float)xscale, xs1 = (float)(1 - xscale), ys = (float)yscale, ys1 = (float)(1 - yscale);
+    Vec3Df       o, d;
+    for (int a = 0; a < 3; ++a) { // corners: origin00 dest00 origin01 dest01 origin10 dest10 origin11 dest11
+        o.p[a] = (corners[a] * xs + corners[12 + a] * xs1) * ys + (corners[6 + a] * xs + corners[18 + a] * xs1) * ys1;
+        d.p[a] = (corners[3 + a] * xs + corners[15 + a] * xs1) * ys + (corners[9 + a] * xs + corners[21 + a] * xs1) * ys1;
+    }
+    const std::string before = g_error;
+    g_error.clear();
+    float depth = focusDepth;
+    performRayTracing(o, d, 0, 0.0f, depth);
+    if (!g_error.empty()) return false;
+    g_error = before;
+    focusDepth = depth;
+    fprintf(stderr, "Focus depth set to %f\n", focusDepth);
+    return true;
+}
+
 double RayTracer::doDaRayTracingShizz(const char* out_dir)
 {
     if (!g_scene) {
@@ -266,6 +287,25 @@ double rth_render_to_files(const char* obj_path, const char* camera_sav, int w, 
     RayTracer    r(modelview, w, h);
     const double secs = r.doDaRayTracingShizz(out_dir);
     if (stats) *stats = r.stats;
+    shutdown();
+    return secs;
+}
+// the same after key 'f' at pixel (fx, fy); *focus receives the focus depth used
+double rth_render_to_files_focus(const char* obj_path, const char* camera_sav, int w, int h, int msaa,
+                                 const char* out_dir, int device, double fx, double fy, float* focus,
+                                 RtStats* stats)
+{
+    if (!init(obj_path, device, true)) return -1.0;
+    double modelview[16];
+    if (!readCameraSav(camera_sav, modelview, MyLightPositions)) return -2.0;
+    MySettings.msaa = msaa;
+    RayTracer r(modelview, w, h);
+    focusDepth = 0.0f;
+    if (!r.setFocusAtPixel(fx, fy)) return -3.0;
+    if (focus) *focus = focusDepth;
+    const double secs = r.doDaRayTracingShizz(out_dir);
+    if (stats) *stats = r.stats;
+    focusDepth = 0.0f;
     shutdown();
     return secs;
 }

@@ -115,6 +115,10 @@ public:
     // main.cpp:322: renders and writes result.ppm, result.bmp, depth.bmp and
     // blurred.bmp into out_dir; returns the seconds the frame took, < 0 on error.
     double doDaRayTracingShizz(const char* out_dir = ".");
+    // Key 'f' (raytracing.cpp:504-507): focusDepth = depth of what the ray through pixel (x, y)
+    // hits, traced as performRayTracing(origin, dest, 0, 0.0f, focusDepth); the ray is the one
+    // raytrace() builds for that pixel (main.cpp:514-529).  Returns false when the GPU call fails.
+    bool setFocusAtPixel(double x, double y);
     Image   result;
     RtStats stats{};
     float   corners[24];

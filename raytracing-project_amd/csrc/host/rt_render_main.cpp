@@ -3,7 +3,8 @@
 // has restored camera.sav (main.cpp:281-307); this program does the same two
 // steps from the command line and writes the same four files.
 //
-// usage: rt_render <scene.obj> <camera.sav> <width> <height> [msaa=1] [out_dir=.] [device=0]
+// usage: rt_render <scene.obj> <camera.sav> <width> <height> [msaa=1] [out_dir=.] [device=0] [focus_x focus_y]
+// focus_x focus_y: key 'f' with the mouse over that pixel before the render (raytracing.cpp:504-507)
 #include <cstdio>
 #include <cstdlib>
 
@@ -12,7 +13,7 @@
 int main(int argc, char** argv)
 {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <scene.obj> <camera.sav> <width> <height> [msaa] [out_dir] [device]\n",
+        fprintf(stderr, "usage: %s <scene.obj> <camera.sav> <width> <height> [msaa] [out_dir] [device] [focus_x focus_y]\n",
                 argv[0]);
         return 2;
     }
@@ -31,6 +32,10 @@ int main(int argc, char** argv)
     }
     rtamd::MySettings.msaa = msaa;
     rtamd::RayTracer tracer(modelview, w, h);
+    if (argc > 9 && !tracer.setFocusAtPixel(atof(argv[8]), atof(argv[9]))) {
+        fprintf(stderr, "focus pick failed: %s\n", rtamd::lastError().c_str());
+        return 1;
+    }
     const double     secs = tracer.doDaRayTracingShizz(out);
     if (secs < 0) {
         fprintf(stderr, "render failed: %s\n", rtamd::lastError().c_str());

@@ -37,7 +37,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef WF_BLOCK
 #define WF_BLOCK 256
+#endif
 #define WF_MAX_DEPTH 6 // ray levels k = 0..5 (raytracing.cpp:63,166-168)
 #define WF_FIX_SCALE 4294967296.0
 

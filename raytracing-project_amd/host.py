@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librt_host.so")
 EXPORTS = ["rth_scene_load", "rth_scene_free", "rth_scene_desc", "rth_tree_depth",
            "rth_material_name", "rth_read_camera_sav", "rth_camera_corners", "rth_write_ppm",
            "rth_write_bmp", "rth_write_depth_bmp", "rth_write_blurred_bmp", "rth_render_to_files",
-           "rth_last_error", "rth_decode_png"]
+           "rth_last_error", "rth_decode_png", "rth_render_to_files_focus"]
 
 _lib = None
 
@@ -46,6 +46,9 @@ def lib():
     L.rth_render_to_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                       C.c_int, C.POINTER(capi.RtStats)]
     L.rth_last_error.restype = C.c_char_p
+    L.rth_render_to_files_focus.restype = C.c_double
+    L.rth_render_to_files_focus.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                            C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), P]
     L.rth_decode_png.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), P, C.c_size_t]
     _lib = L
     return L
@@ -183,3 +186,14 @@ def render_to_files(obj_path, camera_sav, W, H, msaa, out_dir, device=0):
     if secs < 0:
         raise RuntimeError(lib().rth_last_error().decode(errors="replace"))
     return secs, st
+
+
+def render_to_files_focus(obj_path, camera_sav, W, H, msaa, out_dir, fx, fy, device=0):
+    """The 'r' path after key 'f' at pixel (fx, fy): returns (seconds, focus depth, RtStats)."""
+    st = capi.RtStats()
+    focus = C.c_float(0)
+    secs = lib().rth_render_to_files_focus(os.fsencode(obj_path), os.fsencode(camera_sav), W, H, msaa,
+                                           os.fsencode(out_dir), device, fx, fy, C.byref(focus), C.byref(st))
+    if secs < 0:
+        raise RuntimeError(lib().rth_last_error().decode(errors="replace"))
+    return secs, focus.value, st

@@ -181,6 +181,39 @@ def test_r_path_files_match_oracle_writers(P, oracle, tmp_path):
         assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.99, (f, d.max(), (d > 1).sum())
 
 
+def test_focus_pick_then_r_path(P, oracle, tmp_path):
+    """Key 'f' over a pixel, then 'r': a focus depth other than 0 makes the two depth
+    normalisations differ (imageWriter.h:124-135, 352, 416); files against the oracle's."""
+    name, W, H, msaa = "final", 150, 90, 1
+    fx, fy = 60.0, 55.0
+    obj, sav = os.path.join(SCENES, name + ".obj"), os.path.join(SCENES, "cameras", name + ".sav")
+    secs, focus, st = P.host.render_to_files_focus(obj, sav, W, H, msaa, str(tmp_path), fx, fy)
+    s = oracle.Scene.load(obj)
+    m, lights = oracle.read_camera_sav(sav)
+    s.set_lights(lights)
+    s.settings.MSAA = msaa
+    corners = oracle.camera_corners(m, W, H)
+    o, d = oracle.pixel_ray(corners, W, H, fx, fy)
+    _, min_t, tri = s.trace_rays(o[None], d[None])
+    assert tri[0] >= 0 and focus == min_t[0] and 0 < focus < 1     # bit-equal depth of the picked point
+    rgb, depth, _ = s.render(corners, W, H, threads=8)
+    L = oracle.lib()
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    dn = oracle.normalize_depth(depth, focus)
+    L.or_write_depth_bmp(str(ref / "depth.bmp").encode(), None, dn.reshape(-1), W, H)
+    dn2 = oracle.normalize_depth(dn, focus)
+    assert not np.array_equal(dn, dn2)
+    blur = oracle.blur(rgb, dn2, threads=8)
+    L.or_write_blurred_bmp(str(ref / "blurred.bmp").encode(), blur.reshape(-1), W, H)
+    for f in ("depth.bmp", "blurred.bmp"):
+        a = np.frombuffer((tmp_path / f).read_bytes(), np.uint8)
+        b = np.frombuffer((ref / f).read_bytes(), np.uint8)
+        assert a.size == b.size and np.array_equal(a[:54], b[:54]), f
+        dd = np.abs(a[54:].astype(int) - b[54:].astype(int))
+        assert (dd <= 1).mean() >= 0.999 and (dd == 0).mean() >= 0.99, (f, dd.max(), (dd > 1).sum())
+
+
 FC = json.load(open(os.path.join(GOLDEN, "frame_counters.json"))) \
     if os.path.exists(os.path.join(GOLDEN, "frame_counters.json")) else {}
 
