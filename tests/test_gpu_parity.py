@@ -100,3 +100,46 @@ def test_render_frame_matches_oracle(oracle, name, msaa, W, H):
     both = ~miss & (depth != np.float32(3.402823466e+38))
     assert np.allclose(depth[both], odepth[both], rtol=1e-5, atol=0) or \
         (np.abs(depth[both] - odepth[both]) <= 1e-5 * np.abs(odepth[both])).mean() >= 0.9995
+
+
+def test_degenerate_and_extreme_triangles(oracle, tmp_path):
+    """A scene made to leave the common path of the triangle test: a ray parallel to the
+    triangles (determinant exactly 0: a "hit" at the ray origin, Matrix33.h:132-134),
+    triangles 1e-5 and 1e4 units large (determinants far outside the range where the
+    certain-rejection shortcuts apply), rays grazing edges and vertices.  GPU against the
+    oracle, bit for bit.  Which triangle a determinant-0 pseudo-hit is credited to depends
+    on which triangles a walk happens to test (the reference tests every triangle on the root
+    paths of the leaves it visits, the GPU those of the cells the ray crosses), so for such
+    rays only the hit itself is compared."""
+    rng = np.random.default_rng(77)
+    v = [(0, 0, 0), (1, 0, 0), (0, 1, 0),                      # unit triangle in z = 0
+         (3, 0, 0), (3.00001, 0, 0), (3, 0.00001, 0),          # tiny
+         (-5000, -5000, -3), (5000, -5000, -3), (0, 9000, -3),  # huge
+         (0, 0, 1), (1, 0, 1), (0, 1, 1)]                      # a second unit triangle above the first
+    obj = tmp_path / "odd.obj"
+    obj.write_text("".join(f"v {x} {y} {z}\n" for x, y, z in v) +
+                   "".join(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n" for i in range(4)))
+    s = oracle.Scene.load(str(obj))
+    gs = gpu_scene_from_oracle(s)
+    o = [[5, 5, 1.0], [0.25, 0.25, 5], [0, 0, 5], [1, 0, 5], [0.5, 0.5, 5], [3.000003, 0.000003, 4],
+         [0.3, 0.3, 0.5], [0.3, 0.3, -1], [2, 2, 5]]
+    d = [[6, 5, 1.0], [0.25, 0.25, -5], [0, 0, -5], [1, 0, -5], [0.5, 0.5, -5], [3.000003, 0.000003, -4],
+         [0.3, 0.3, 3], [0.3, 0.3, -2], [2, 2, -5]]
+    lo, hi = np.float32([-2, -2, -4]), np.float32([4, 4, 3])
+    ro = (lo + (hi - lo) * rng.random((20000, 3))).astype(np.float32)
+    rv = rng.normal(size=(20000, 3))
+    rd = (ro + 10 * rv / np.linalg.norm(rv, axis=1, keepdims=True)).astype(np.float32)
+    o = np.concatenate([np.float32(o), ro])
+    d = np.concatenate([np.float32(d), rd])
+    tri, a, b, t, hp = gs.check_hits(o, d)
+    rtri, ra, rb, rt_, rhp = s.check_hits(o, d, threads=4)
+    pseudo = (rt_ == 0) & np.signbit(rt_) & (rtri >= 0)
+    assert pseudo[0] and pseudo.sum() < 10
+    assert (tri[pseudo] >= 0).all() and (t[pseudo] == 0).all() and np.signbit(t[pseudo]).all()
+    assert np.array_equal(hp[pseudo], rhp[pseudo])              # the ray origin
+    real = ~pseudo
+    assert np.array_equal(tri[real], rtri[real])
+    hit = real & (rtri >= 0)
+    assert hit.sum() > 1000 and len(set(rtri[hit].tolist())) == 4
+    for g, r in ((a, ra), (b, rb), (t, rt_), (hp, rhp)):
+        assert np.array_equal(g[hit].view(np.uint32), r[hit].view(np.uint32))
