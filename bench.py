@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered concurrently per GPU (each with its own workspace and stream); "
+                         "default 1 on one GPU, 2 on several")
     args = ap.parse_args()
 
     import torch
@@ -108,17 +111,30 @@ def main():
     import ctypes as C
 
     hs = host.HostScene(os.path.join(ROOT, "scenes", SCENE + ".obj"))
-    gs = hs.to_gpu(local)
     m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", SCENE + ".sav"))
     corners = host.camera_corners(m, W, H)
     p = capi.default_params(W, H, MSAA)
     p.tile_w = p.tile_h = TILE
-
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    depth = torch.zeros((H, W), dtype=torch.float32, device=dev)
-    blurred = torch.zeros((H - 12, W - 12, 3), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
     L = capi.lib()
+
+    # Frames in flight.  A rank's part of the frame is one persistent launch whose last regions
+    # run on a nearly idle GPU (about 1 ms, whatever the size of the part).  With several GPUs
+    # that tail is a third of the launch, so consecutive frames are issued on two streams, each
+    # with its own scene workspace and frame buffers: the blocks of frame i + 1 start as those of
+    # frame i retire, and on rank 0 the post-process of frame i overlaps the render of i + 1.
+    # On one GPU the frames run one after the other, so that the launch durations behind the
+    # roofline figure are those of a launch that has the GPU to itself.
+    n_flight = args.frames_in_flight or (1 if world == 1 else 2)
+    slots = []
+    for i in range(n_flight):
+        st_ = torch.cuda.Stream(device=dev) if n_flight > 1 else torch.cuda.current_stream()
+        slots.append({"gs": hs.to_gpu(local), "stream": st_,
+                      "rgb": torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
+                      "depth": torch.zeros((H, W), dtype=torch.float32, device=dev),
+                      "blurred": torch.zeros((H - 12, W - 12, 3), dtype=torch.float32, device=dev),
+                      "ev": [torch.cuda.Event(enable_timing=True) for _ in range(2)]})
+    gs = slots[0]["gs"]
+    rgb, depth = slots[0]["rgb"], slots[0]["depth"]
     PER_RANK = 16   # shares per GPU in the deal; rank 0 may own fewer (it also runs the post-process)
     state = {}
 
@@ -129,41 +145,44 @@ def main():
         p.rank, p.rank_span = deal[rank]
         p.world = n_shares
         n_slots = L.rt_tile_pixels(C.byref(p), p.rank)
-        state.update(deal=(n_shares, deal), first_rank_shares=deal[0][1],
-                     payload=torch.zeros((max(n_slots, 1), 4), dtype=torch.float32, device=dev)[:n_slots])
+        state.update(deal=(n_shares, deal), first_rank_shares=deal[0][1])
+        for sl in slots:
+            sl["payload"] = torch.zeros((max(n_slots, 1), 4), dtype=torch.float32, device=dev)[:n_slots]
 
     set_deal(PER_RANK)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def unpack(src, buf):
-        ps = capi.RtParams.from_buffer_copy(p)      # the source rank's shares
-        ps.rank, ps.rank_span = state["deal"][1][src]
-        capi.check(L.rt_unpack_tiles_device(local, C.byref(ps), ps.rank, C.c_void_p(buf.data_ptr()),
-                                            C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
-                                            C.c_void_p(stream)))
+    def frame(i=0, stats=False):
+        sl = slots[i % n_flight]
+        with torch.cuda.stream(sl["stream"]):
+            stream = sl["stream"].cuda_stream
+            d_rgb, d_depth = C.c_void_p(sl["rgb"].data_ptr()), C.c_void_p(sl["depth"].data_ptr())
 
-    def frame(stats=False):
-        st = gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, stream, stats)
-        if world > 1:
-            payload = state["payload"]
-            capi.check(L.rt_pack_tiles_device(local, C.byref(p), C.c_void_p(rgb.data_ptr()),
-                                              C.c_void_p(depth.data_ptr()),
-                                              C.c_void_p(payload.data_ptr()), C.c_void_p(stream)))
-            if backend == "gloo":
-                pkg.distributed.gather_frame(payload.cpu(), W, H, TILE, TILE, rank, world, dist,
-                                             lambda src, buf: unpack(src, buf.to(dev)), state["deal"])
-            else:
-                pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack, state["deal"])
-        if rank == 0:
-            ev[0].record()
-            # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
-            for _ in range(2):
-                capi.check(L.rt_normalize_depth_device(local, W * H, p.focusDepth,
-                                                       C.c_void_p(depth.data_ptr()), C.c_void_p(stream)))
-            capi.check(L.rt_dof_blur_device(local, W, H, p.depthPower, C.c_void_p(rgb.data_ptr()),
-                                            C.c_void_p(depth.data_ptr()),
-                                            C.c_void_p(blurred.data_ptr()), C.c_void_p(stream)))
-            ev[1].record()
+            def unpack(src, buf):
+                ps = capi.RtParams.from_buffer_copy(p)      # the source rank's shares
+                ps.rank, ps.rank_span = state["deal"][1][src]
+                capi.check(L.rt_unpack_tiles_device(local, C.byref(ps), ps.rank, C.c_void_p(buf.data_ptr()),
+                                                    d_rgb, d_depth, C.c_void_p(stream)))
+
+            st = sl["gs"].render_device(corners, lights, p, sl["rgb"].data_ptr(), sl["depth"].data_ptr(), 0,
+                                        stream, stats)
+            if world > 1:
+                payload = sl["payload"]
+                capi.check(L.rt_pack_tiles_device(local, C.byref(p), d_rgb, d_depth,
+                                                  C.c_void_p(payload.data_ptr()), C.c_void_p(stream)))
+                if backend == "gloo":
+                    pkg.distributed.gather_frame(payload.cpu(), W, H, TILE, TILE, rank, world, dist,
+                                                 lambda src, buf: unpack(src, buf.to(dev)), state["deal"])
+                else:
+                    pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack,
+                                                 state["deal"])
+            if rank == 0:
+                sl["ev"][0].record()
+                # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
+                for _ in range(2):
+                    capi.check(L.rt_normalize_depth_device(local, W * H, p.focusDepth, d_depth, C.c_void_p(stream)))
+                capi.check(L.rt_dof_blur_device(local, W, H, p.depthPower, d_rgb, d_depth,
+                                                C.c_void_p(sl["blurred"].data_ptr()), C.c_void_p(stream)))
+                sl["ev"][1].record()
         return st
 
     def barrier():
@@ -184,7 +203,7 @@ def main():
             frame()
             torch.cuda.synchronize()
             if rank == 0:
-                post += ev[0].elapsed_time(ev[1]) / n
+                post += slots[0]["ev"][0].elapsed_time(slots[0]["ev"][1]) / n
         kt_ = gs.collect_timing()
         gs.set_timing(False)
         return kt_.frame_ms / max(kt_.frames, 1), post
@@ -216,7 +235,8 @@ def main():
         set_deal(shares0)
 
     # one counted frame: rays this rank traces per frame (deterministic)
-    st = frame(stats=True)
+    st = frame(0, stats=True)
+    torch.cuda.synchronize()
     my_rays = st.rays_closest + st.rays_shadow
     my = torch.tensor([float(my_rays), float(st.tri_tests), float(st.node_visits)],
                       dtype=torch.float64, device=dev)
@@ -229,17 +249,22 @@ def main():
             dist.all_reduce(my)
     rays_per_frame, tests_per_frame, nodes_per_frame = (float(x) for x in my.tolist())
 
-    for _ in range(args.warmup):
-        frame()
-    gs.set_timing(True)
+    for i in range(args.warmup):
+        frame(i)
+    for sl in slots:
+        sl["gs"].set_timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
+    for i in range(args.steps):
+        frame(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    kt = gs.collect_timing()
-    gs.set_timing(False)
+    kt = capi.RtKernelTimes()
+    for sl in slots:
+        k_ = sl["gs"].collect_timing()
+        kt.frame_ms += k_.frame_ms
+        kt.frames += k_.frames
+        sl["gs"].set_timing(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         if backend == "gloo":
@@ -252,9 +277,9 @@ def main():
         p1 = capi.default_params(W, H, MSAA)
         rgb1 = torch.zeros_like(rgb)
         depth1 = torch.zeros_like(depth)
-        gs.render_device(corners, lights, p1, rgb1.data_ptr(), depth1.data_ptr(), 0, stream, False)
+        gs.render_device(corners, lights, p1, rgb1.data_ptr(), depth1.data_ptr(), 0, 0, False)
         torch.cuda.synchronize()
-        same = bool((rgb1 == rgb).all().item())
+        same = all(bool((rgb1 == sl["rgb"]).all().item()) for sl in slots[:max(1, min(n_flight, args.steps))])
         print(f"partition check: gathered frame {'equals' if same else 'DIFFERS FROM'} the single-GPU frame",
               file=sys.stderr, flush=True)
         if not same:
@@ -313,13 +338,17 @@ def main():
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
                         "traffic": traffic, "kernel_ms": round(kern_ms, 3),
                         "launches_per_frame": round(kt.frames / args.steps, 2),
+                        "frames_in_flight": n_flight,
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "frac_reference_walk": round(
                             fc["flops_frame"] * frac0 / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                         "note": "no MFMA on this path: the bound is the FP32 vector peak (= the f32 MFMA "
                                 "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk "
                                 "(T = %d ray/triangle tests, S = %d leaf steps per frame)"
-                                % (fc["frame"]["tri_tests"], fc["frame"]["leaf_steps"]),
+                                % (fc["frame"]["tri_tests"], fc["frame"]["leaf_steps"])
+                                + ("" if n_flight == 1 else "; with %d frames in flight a launch shares the GPU with "
+                                   "the next one, its HIP-event duration is longer than its share of the GPU and "
+                                   "this figure understates the kernel" % n_flight),
                         "frame": {"ms_incl_dof_and_gather": round(ms, 3),
                                   "achieved_tflops": round(f_needed / (ms * 1e-3) / 1e12, 3),
                                   "frac": round(f_needed / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS / world, 4),
@@ -331,8 +360,10 @@ def main():
         if calib:
             out["config"]["load_balance_calibration"] = calib
         out["roofline"] = roof
-        out["kernel_ms"] = {"k_wf_pipeline": round(kt.frame_ms / max(kt.frames, 1), 3),
-                            "dof_and_gather": round(ms - kt.frame_ms / max(kt.frames, 1), 3)}
+        out["kernel_ms"] = {"k_wf_pipeline": round(kt.frame_ms / max(kt.frames, 1), 3)}
+        if n_flight == 1:
+            out["kernel_ms"]["dof_and_gather"] = round(ms - kt.frame_ms / max(kt.frames, 1), 3)
+        out["config"]["frames_in_flight"] = n_flight
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)
         print(json.dumps(out), flush=True)

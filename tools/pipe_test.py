@@ -1,0 +1,43 @@
+"""Experiment: frames of one config pipelined D deep (one scene workspace and one stream per slot)."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("raytracing-project_amd")
+capi, host = pkg.capi, pkg.host
+import torch
+name, W, H, msaa = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+depth_n = int(sys.argv[5]); frames = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+hs = host.HostScene(os.path.join(ROOT, "scenes", name + ".obj"))
+m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
+corners = host.camera_corners(m, W, H)
+p = capi.default_params(W, H, msaa)
+if os.environ.get("WORLD"):
+    p.tile_w = p.tile_h = 32; p.world = int(os.environ["WORLD"]); p.rank = int(os.environ.get("RANK", "0"))
+slots = []
+for i in range(depth_n):
+    gs = hs.to_gpu(0)
+    slots.append(dict(gs=gs, st=torch.cuda.Stream(), rgb=torch.zeros((H, W, 3), device="cuda"),
+                      depth=torch.zeros((H, W), device="cuda"), blur=torch.zeros((H - 12, W - 12, 3), device="cuda")))
+def frame(i):
+    s = slots[i % depth_n]
+    with torch.cuda.stream(s["st"]):
+        s["gs"].render_device(corners, lights, p, s["rgb"].data_ptr(), s["depth"].data_ptr(), 0,
+                              s["st"].cuda_stream, False)
+        if os.environ.get("POST") == "1":   # rank 0's post-process on the same stream
+            import ctypes as C
+            L = capi.lib()
+            for _ in range(2):
+                capi.check(L.rt_normalize_depth_device(0, W * H, p.focusDepth, C.c_void_p(s["depth"].data_ptr()),
+                                                       C.c_void_p(s["st"].cuda_stream)))
+            capi.check(L.rt_dof_blur_device(0, W, H, p.depthPower, C.c_void_p(s["rgb"].data_ptr()),
+                                            C.c_void_p(s["depth"].data_ptr()), C.c_void_p(s["blur"].data_ptr()),
+                                            C.c_void_p(s["st"].cuda_stream)))
+for i in range(4): frame(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(frames): frame(i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / frames * 1e3
+same = all(bool((s["rgb"] == slots[0]["rgb"]).all().item()) for s in slots)
+if os.environ.get("RANK_SPAN"): pass
+print(f"{name} {W}x{H} msaa{msaa} depth {depth_n} world {p.world}: {dt:.3f} ms/frame, frames equal: {same}")
