@@ -1,4 +1,7 @@
-"""Experiment: frames of one config pipelined D deep (one scene workspace and one stream per slot)."""
+"""Experiment: frames of one config pipelined D deep (one scene workspace and one stream per slot).
+
+  [WORLD=n RANK=r] [POST=1] python tools/pipe_test.py <scene> <W> <H> <msaa> <depth> [frames]
+POST=1 adds rank 0's depth passes and blur on the slot's stream."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -39,5 +42,4 @@ for i in range(frames): frame(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / frames * 1e3
 same = all(bool((s["rgb"] == slots[0]["rgb"]).all().item()) for s in slots)
-if os.environ.get("RANK_SPAN"): pass
 print(f"{name} {W}x{H} msaa{msaa} depth {depth_n} world {p.world}: {dt:.3f} ms/frame, frames equal: {same}")
