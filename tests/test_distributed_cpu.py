@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, w0=None):
     import importlib
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -45,25 +45,35 @@ def _worker(rank, world, port, outdir):
         rgb, minT, _ = s.trace_rays(o, d)
         return np.clip(rgb, 0, 1), minT
 
-    payload = pkg.distributed.render_cpu_partition(shade, W, H, TW, TH, rank, world)
+    # even deal: one share per rank; uneven: rank 0 owns fewer shares than the others
+    deal = (world, [(r, 1) for r in range(world)]) if w0 is None else pkg.tiles.shares(world, w0, per_rank=4)
+    n_shares, (first, span) = deal[0], deal[1][rank]
+    x, y, ok = pkg.tiles.slot_pixels(W, H, TW, TH, first, n_shares, span)
+    payload = np.zeros((len(x), 4), np.float32)
+    if ok.any():
+        c, dpt = shade(x[ok], y[ok])
+        payload[ok, :3], payload[ok, 3] = c, dpt
+    if w0 is None:                                   # the helper states the same for the even deal
+        assert np.array_equal(payload, pkg.distributed.render_cpu_partition(shade, W, H, TW, TH, rank, world))
     rgb = np.zeros((H, W, 3), np.float32)
     depth = np.zeros((H, W), np.float32)
 
     def unpack(src, buf):
-        pkg.tiles.unpack(buf.numpy(), rgb, depth, TW, TH, src, world)
+        f, sp = deal[1][src]
+        pkg.tiles.unpack(buf.numpy(), rgb, depth, TW, TH, f, n_shares, sp)
 
-    pkg.distributed.gather_frame(torch.from_numpy(payload), W, H, TW, TH, rank, world, dist, unpack)
+    pkg.distributed.gather_frame(torch.from_numpy(payload), W, H, TW, TH, rank, world, dist, unpack, deal)
     if rank == 0:
         np.savez(os.path.join(outdir, "frame.npz"), rgb=rgb, depth=depth)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_ranks_rebuild_the_frame(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,w0", [(2, None), (3, None), (2, 0.5), (3, 0.25)])
+def test_two_ranks_rebuild_the_frame(oracle, tmp_path, world, w0):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), w0), nprocs=world, join=True)
     got = np.load(tmp_path / "frame.npz")
     s = oracle.Scene.load(os.path.join(SCENES, "redballs.obj"))
     m, lights = oracle.read_camera_sav(os.path.join(SCENES, "cameras", "redballs.sav"))
