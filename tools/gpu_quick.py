@@ -1,18 +1,20 @@
-"""Scratch GPU check: renders the BASELINE configs once and prints timing + stats."""
-import os, sys, time
-import numpy as np
+"""GPU check: renders the five BASELINE configs once and prints timing + stats."""
+import importlib
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import gpu_scene_from_oracle, pkg
-from oracle import oracle as O
-capi = pkg().capi
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("raytracing-project_amd")
+capi, host = pkg.capi, pkg.host
 cfgs = [("ball", 800, 800, 1), ("redballs", 1920, 1080, 1), ("refractionballs", 1920, 1080, 1),
         ("lego", 3840, 2160, 4), ("final", 3840, 2160, 4)]
 for name, W, H, msaa in cfgs:
-    s = O.Scene.load(os.path.join(ROOT, "scenes", name + ".obj"))
-    m, lights = O.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
-    gs = gpu_scene_from_oracle(s)
-    corners = O.camera_corners(m, W, H)
+    hs = host.HostScene(os.path.join(ROOT, "scenes", name + ".obj"))
+    m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
+    gs = hs.to_gpu(0)
+    corners = host.camera_corners(m, W, H)
     p = capi.default_params(W, H, msaa)
     for it in range(2):
         t = time.time()
