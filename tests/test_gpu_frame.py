@@ -358,3 +358,27 @@ def test_bench_two_ranks_rehearsal():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["roofline"]["kernel"] == "k_wf_pipeline" and "cpu_baseline" not in out
+
+
+def test_rt_render_program(P, tmp_path):
+    """The headless 'r' key as a program of its own (C++ host + librt_hip.so, no Python, no
+    torch in the process): same four files as the library path, byte for byte."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracing-project_amd", "csrc", "rt_render")
+    assert os.path.exists(exe), "rt_render is built by raytracing-project_amd/build.py"
+    obj, sav = os.path.join(SCENES, "lego.obj"), os.path.join(SCENES, "cameras", "lego.sav")
+    a, b = tmp_path / "prog", tmp_path / "lib"
+    a.mkdir(), b.mkdir()
+    env = dict(os.environ)
+    libdir = os.path.dirname(exe)
+    env["LD_LIBRARY_PATH"] = libdir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe, obj, sav, "192", "108", "4", str(a), "0", "100", "60"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "closest" in r.stdout and "Focus depth set to" in r.stderr
+    P.host.render_to_files_focus(obj, sav, 192, 108, 4, str(b), 100.0, 60.0)
+    for f in ("result.ppm", "result.bmp", "depth.bmp", "blurred.bmp"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    bad = subprocess.run([exe, obj], env=env, capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "usage" in bad.stderr
