@@ -382,3 +382,18 @@ def test_rt_render_program(P, tmp_path):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
     bad = subprocess.run([exe, obj], env=env, capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2 and "usage" in bad.stderr
+
+
+@pytest.mark.parametrize("W,H", [(13, 13), (14, 13), (45, 21), (77, 20), (44, 33)])
+def test_dof_blur_ragged_sizes(P, oracle, W, H):
+    """Frames from the smallest the blur accepts (one output pixel) through sizes that leave
+    partial 32x8 blocks on both edges."""
+    rng = np.random.default_rng(W * 100 + H)
+    rgb = rng.random((H, W, 3), dtype=np.float32)
+    dn = rng.random((H, W), dtype=np.float32) * 0.9
+    dn[H // 2, W // 2] = 0.0
+    got, ref = P.capi.dof_blur(rgb, dn), oracle.blur(rgb, dn, threads=2)
+    assert got.shape == ref.shape == (H - 12, W - 12, 3)
+    assert np.abs(got - ref).max() < 2e-6
+    q, oq = P.capi.quantize(got), oracle.to_bytes(ref)
+    assert (np.abs(q.astype(int) - oq.astype(int)) <= 1).all()

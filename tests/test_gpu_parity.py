@@ -143,3 +143,57 @@ def test_degenerate_and_extreme_triangles(oracle, tmp_path):
     assert hit.sum() > 1000 and len(set(rtri[hit].tolist())) == 4
     for g, r in ((a, ra), (b, rb), (t, rt_), (hp, rhp)):
         assert np.array_equal(g[hit].view(np.uint32), r[hit].view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_scenes_match_oracle(oracle, seed):
+    """Scenes no fixture knows: a few hundred random triangles (a soup: they intersect each
+    other, many share no vertex) with diffuse, mirror and refractive materials, four lights.
+    Closest hits bit for bit, ray colours and a small MSAA frame within the 8-bit bar."""
+    rng = np.random.default_rng(seed)
+    n_tri = 300 + 100 * (seed % 3)
+    centre = rng.uniform(-2, 2, (n_tri, 1, 3))
+    size = rng.choice([0.05, 0.3, 1.5], (n_tri, 1, 1))
+    vpos = (centre + size * rng.normal(size=(n_tri, 3, 3))).reshape(-1, 3).astype(np.float32)
+    floor = np.float32([[-6, -6, -2.5], [6, -6, -2.5], [6, 6, -2.5], [-6, 6, -2.5]])
+    vpos = np.concatenate([vpos, floor])
+    tri_v = np.concatenate([np.arange(3 * n_tri).reshape(-1, 3), 3 * n_tri + np.int32([[0, 1, 2], [0, 2, 3]])])
+    mats = np.zeros((4, 16), np.float32)
+    #          Kd               Ks               Ns  Ni   illum has_Ni
+    mats[0, :10] = [0.8, 0.3, 0.2, 0.5, 0.5, 0.5, 40, 1.0, 2, 1]      # diffuse
+    mats[1, :10] = [0.2, 0.2, 0.9, 1.0, 1.0, 1.0, 96, 1.0, 3, 1]      # mirror
+    mats[2, :10] = [0.9, 0.9, 0.9, 0.3, 0.3, 0.3, 20, 1.3, 2, 1]      # refractive
+    mats[3, :10] = [0.3, 0.8, 0.3, 0.0, 0.0, 0.0, 5, 1.0, 2, 0]       # diffuse, no Ni line
+    tri_mat = np.concatenate([rng.integers(0, 4, n_tri), [0, 3]]).astype(np.int32)
+    s = oracle.Scene.from_arrays(vpos, tri_v, tri_mat, mats)
+    lights = np.float32([[0, 0, 6], [4, -3, 5], [-5, 2, 1], [1, 5, -1]])
+    s.set_lights(lights)
+    gs = gpu_scene_from_oracle(s)
+    o = rng.uniform(-5, 5, (30000, 3)).astype(np.float32)
+    v = rng.normal(size=(30000, 3))
+    d = (o + 10 * v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    tri, a, b, t, hp = gs.check_hits(o, d)
+    rtri, ra, rb, rt_, rhp = s.check_hits(o, d, threads=4)
+    same = tri == rtri
+    assert same.mean() >= 0.9999
+    hit = same & (rtri >= 0)
+    assert hit.mean() > 0.3
+    for g, r in ((a, ra), (b, rb), (t, rt_), (hp, rhp)):
+        assert np.array_equal(g[hit].view(np.uint32), r[hit].view(np.uint32))
+    rgb, mt, tri2, _ = gs.trace_rays(o[:8000], d[:8000], lights)
+    orgb, omt, otri = s.trace_rays(o[:8000], d[:8000], threads=4)
+    ok = tri2 == otri
+    assert ok.mean() >= 0.9999
+    q, oq = oracle.to_bytes(np.clip(rgb[ok], 0, 1)), oracle.to_bytes(np.clip(orgb[ok], 0, 1))
+    assert (np.abs(q.astype(int) - oq.astype(int)) <= 1).mean() >= 0.999
+    # a frame through the wavefront pipeline (refraction: two children per hit)
+    W, H = 120, 80
+    m = np.float64([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, -7, 1])
+    corners = oracle.camera_corners(m, W, H)
+    s.settings.MSAA = 4
+    frgb, fdepth, ftri = s.render(corners, W, H, threads=8)
+    grgb, gdepth, gtri, st = gs.render(corners, lights, pkg().capi.default_params(W, H, 4))
+    assert (gtri == ftri).mean() >= 0.999
+    diff = np.abs(oracle.to_bytes(grgb).astype(int) - oracle.to_bytes(frgb).astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} of {diff.size} pixels off by > 1 LSB"
+    assert st.rays_closest > W * H
