@@ -81,7 +81,10 @@ def test_trace_rays_untextured_match_reference(oracle, name):
 @pytest.mark.parametrize("name,msaa,W,H", [("ball", 1, 200, 200), ("redballs", 1, 240, 135),
                                           ("refractionballs", 1, 240, 135),
                                           ("lego", 4, 240, 135), ("final", 4, 240, 135),
-                                          ("final", 16, 96, 54), ("lego", 1, 101, 67)])
+                                          ("final", 16, 96, 54), ("lego", 1, 101, 67),
+                                          # ragged and minimal frames: partial tiles, partial 8x8 blocks, 2x2
+                                          ("ball", 4, 2, 2), ("final", 4, 33, 17), ("refractionballs", 1, 65, 3),
+                                          ("lego", 16, 9, 31)])
 def test_render_frame_matches_oracle(oracle, name, msaa, W, H):
     s, g = _scene(oracle, name)
     gs = gpu_scene_from_oracle(s)
