@@ -1221,7 +1221,10 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
     const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8 + 16) + 4 + (size_t)L * 17) +
                               (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
                               (size_t)(2 + 2 * (1 + L)) * 4;
-    long long g_max = (long long)(WF_WORKSPACE_BUDGET / n_pipes / per_region);
+    size_t budget = WF_WORKSPACE_BUDGET;
+    if (const char* b_env = getenv("RT_WF_BUDGET_MB")) // tests: force a frame through several chunks
+        budget = (size_t)std::max(1, atoi(b_env)) << 20;
+    long long g_max = (long long)(budget / n_pipes / per_region);
     g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
     g_max = std::max<long long>(g_max, 1);
     const long long g_need = (n_slots + S - 1) / S;

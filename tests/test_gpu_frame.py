@@ -340,6 +340,31 @@ def test_render_paths_agree(P, oracle, monkeypatch):
     assert a[3].rays_closest == c[3].rays_closest
 
 
+def test_chunked_frame_and_many_lights(P, monkeypatch):
+    """A frame too large for its workspace is rendered in chunks of regions (here forced with
+    a 2 MB budget), in both launch structures; 40 lights stretch the per-light queues.  All
+    must equal the one-chunk frame bit for bit."""
+    hs, gs, m, lights = _host_gpu(P, "final")
+    rng = np.random.default_rng(3)
+    many = np.concatenate([lights, rng.uniform(-6, 6, (37, 3)).astype(np.float32)])
+    W, H = 160, 96
+    corners = P.host.camera_corners(m, W, H)
+    for k in ("RT_WF_MULTILAUNCH", "RT_WF_BUDGET_MB"):
+        monkeypatch.delenv(k, raising=False)
+    whole = gs.render(corners, many, P.capi.default_params(W, H, 4))
+    assert whole[3].rays_shadow > 0
+    for env in ({"RT_WF_BUDGET_MB": "2"}, {"RT_WF_BUDGET_MB": "2", "RT_WF_MULTILAUNCH": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hs2, gs2, _, _ = _host_gpu(P, "final")           # a scene of its own: the workspace is sized per scene
+        part = gs2.render(corners, many, P.capi.default_params(W, H, 4))
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        assert np.array_equal(part[0], whole[0]) and np.array_equal(part[1], whole[1])
+        assert np.array_equal(part[2], whole[2])
+        assert part[3].rays_closest == whole[3].rays_closest and part[3].rays_shadow == whole[3].rays_shadow
+
+
 def test_bench_two_ranks_rehearsal():
     """bench.py as two ranks sharing this GPU, payloads gathered through host memory (gloo):
     the tile partition, pack, gather and unpack path of the N > 1 bench, end to end; the
