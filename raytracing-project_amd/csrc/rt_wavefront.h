@@ -239,22 +239,6 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
             float        a, b, t;
             if (COUNT) ++n_tests;
-#if defined(WF_ABLATE_DOUBLE_TEST) // timing experiment: the arithmetic of the test a second time
-            {
-                float a2, b2, t2;
-                f3    o2 = o;
-                asm volatile("" : "+v"(o2.x));
-                const bool r2 = tri_test(q0, q1, q2, o2, d, minT, a2, b2, t2);
-                asm volatile("" ::"v"(a2), "v"(b2), "v"(t2), "s"((int)r2));
-            }
-#endif
-#if defined(WF_ABLATE_DOUBLE_LOAD) // timing experiment: the triangle loads a second time
-            {
-                const int    s2 = first + ((i + 1) % cnt);
-                const float4 r0 = S.tris[3 * s2], r1 = S.tris[3 * s2 + 1], r2 = S.tris[3 * s2 + 2];
-                asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x), "v"(r0.w), "v"(r1.w), "v"(r2.w));
-            }
-#endif
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
