@@ -114,6 +114,11 @@ def lib():
     L.or_write_depth_bmp.argtypes = [C.c_char_p, C.c_void_p, fp, C.c_int, C.c_int]
     L.or_write_blurred_bmp.restype = C.c_int
     L.or_write_blurred_bmp.argtypes = [C.c_char_p, fp, C.c_int, C.c_int]
+    L.or_write_blurred_bmp2.restype = C.c_int
+    L.or_write_blurred_bmp2.argtypes = [C.c_char_p, fp, C.c_int, C.c_int,
+                                        np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_size_t]
+    L.or_update_bmp_rows.restype = C.c_int
+    L.or_update_bmp_rows.argtypes = [C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -319,6 +324,31 @@ def to_bytes(v):
     out = np.zeros(v.size, np.uint8)
     lib().or_to_bytes(v.reshape(-1), v.size, out)
     return out.reshape(v.shape)
+
+
+def write_result_files(out_dir, rgb, depth, focus=0.0, depth_power=2.5, threads=1):
+    """The files of the 'r' path in the reference's order (main.cpp:325, 404-407, 371-377):
+    progress.bmp (blank result.bmp + one per-row update per row), result.ppm, result.bmp,
+    depth.bmp (depth normalised once), blurred.bmp (normalised twice, then blurred).
+    rgb is the clamped image, depth the raw depth plane.  Returns (depth1, depth2, blurred)."""
+    L = lib()
+    rgb = _f32(rgb)
+    H, W = rgb.shape[:2]
+    p = lambda n: os.fsencode(os.path.join(out_dir, n))  # noqa: E731
+    L.or_write_bmp(p("progress.bmp"), np.zeros_like(rgb).reshape(-1), W, H)
+    for y in range(H):
+        L.or_update_bmp_rows(p("progress.bmp"), rgb.reshape(-1), W, 0, y, W, 1)
+    L.or_write_ppm(p("result.ppm"), rgb.reshape(-1), W, H)
+    L.or_write_bmp(p("result.bmp"), rgb.reshape(-1), W, H)
+    d1 = normalize_depth(depth, focus)
+    L.or_write_depth_bmp(p("depth.bmp"), None, d1.reshape(-1), W, H)
+    d2 = normalize_depth(d1, focus)
+    bl = None
+    if W > 12 and H > 12:
+        bl = blur(rgb, d2, depth_power, threads)
+        prev = np.fromfile(os.path.join(out_dir, "depth.bmp"), np.uint8)[54:].copy()
+        L.or_write_blurred_bmp2(p("blurred.bmp"), bl.reshape(-1), W, H, prev, prev.size)
+    return d1, d2, bl
 
 
 def read_camera_sav(path):

@@ -1583,8 +1583,13 @@ int or_write_depth_bmp(const char *path, const float *rgb_unused, const float *d
     return t == 1;
 }
 
-/* imageWriter.h:406-470; blur is (W-12)*(H-12)*3 */
-int or_write_blurred_bmp(const char *path, const float *blur, int W, int H)
+/* imageWriter.h:406-470; blur is (W-12)*(H-12)*3.  The writers share the member buffer
+ * imageC (imageWriter.h:239) and the padding loop below writes three bytes early, so when
+ * rows need padding the last three bytes of every row keep what the previous writer left:
+ * `prev` (may be NULL = zeros) is that content, n_prev bytes - on the 'r' path the pixel
+ * bytes of depth.bmp (main.cpp:375-377). */
+int or_write_blurred_bmp2(const char *path, const float *blur, int W, int H, const unsigned char *prev,
+                          size_t n_prev)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return 0;
@@ -1594,6 +1599,7 @@ int or_write_blurred_bmp(const char *path, const float *blur, int W, int H)
     fwrite(fh, 1, 14, f), fwrite(ih, 1, 40, f);
     int rowsize = ((24 * bw + 31) / 32) * 4;
     unsigned char *buf = (unsigned char *)calloc((size_t)rowsize * bh + 8, 1);
+    if (prev) memcpy(buf, prev, n_prev < (size_t)rowsize * bh ? n_prev : (size_t)rowsize * bh);
     for (int y = 0; y < bh; ++y) {
         int i = 0;
         for (; i < bw * 3; i += 3) {
@@ -1607,4 +1613,29 @@ int or_write_blurred_bmp(const char *path, const float *blur, int W, int H)
     free(buf);
     fclose(f);
     return t == 1;
+}
+
+int or_write_blurred_bmp(const char *path, const float *blur, int W, int H)
+{
+    return or_write_blurred_bmp2(path, blur, W, H, NULL, 0);
+}
+
+/* imageWriter.h:472-488: the per-row update of an existing result.bmp */
+int or_update_bmp_rows(const char *path, const float *rgb, int W, int x, int y, int w, int h)
+{
+    FILE *f = fopen(path, "r+b");
+    if (!f) return 0;
+    unsigned char *row = (unsigned char *)malloc((size_t)w * 3);
+    for (int Y = y; Y < y + h; ++Y) {
+        for (int j = x; j < x + w; ++j) {
+            row[(j - x) * 3] = to_byte(rgb[(size_t)Y * W * 3 + j * 3 + 2]);
+            row[(j - x) * 3 + 1] = to_byte(rgb[(size_t)Y * W * 3 + j * 3 + 1]);
+            row[(j - x) * 3 + 2] = to_byte(rgb[(size_t)Y * W * 3 + j * 3]);
+        }
+        fseek(f, 54 + ((long)Y * w + x) * 3, SEEK_SET);
+        fwrite(row, 1, (size_t)w * 3, f);
+    }
+    free(row);
+    fclose(f);
+    return 1;
 }

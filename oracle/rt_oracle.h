@@ -7,17 +7,21 @@
  * Every function cites the reference file:line it restates
  * (paths are relative to the reference checkout).
  *
- * Parity status: the KD build, the leaf walk, the ray/triangle test and the
- * shading recursion are pinned against the reference's own sources compiled in
- * the build container (oracle/_ref, see oracle/Makefile); the OBJ/MTL loader,
- * the texture lookup, the frame driver (MSAA) and the image/DoF code are
- * restated from reading the source only - PARITY UNPINNED for those, because
- * the reference files that hold them need libraries or headers this image
- * lacks (Corona, GLU, std::powf).
+ * Parity status: the KD build, the leaf walk, the ray/triangle test, the
+ * shading recursion (raytracing.cpp, KDtree.cpp, mesh.cpp's normals) and the
+ * image code (imageWriter.h: RGBValue clamp, depth normalisation, the 13x13
+ * depth-of-field kernel, the blur, the PPM/BMP writers and the per-row update)
+ * are pinned against the reference's own sources compiled in the build
+ * container (oracle/_ref, see oracle/Makefile; vectors in tests/golden/).
+ * The OBJ/MTL loader, the texture lookup and the frame driver (corner rays,
+ * per-pixel ray, MSAA) are restated from reading the source only - PARITY
+ * UNPINNED for those, because the reference files that hold them need
+ * libraries this image lacks (Corona, GLU/GLUT).
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -150,6 +154,11 @@ int or_write_ppm(const char *path, const float *rgb, int W, int H);
 int or_write_depth_bmp(const char *path, const float *rgb_unused, const float *depthN, int W,
                        int H);
 int or_write_blurred_bmp(const char *path, const float *blur, int W, int H);
+/* prev: what the previous writer left in the shared byte buffer (NULL = zeros) */
+int or_write_blurred_bmp2(const char *path, const float *blur, int W, int H, const unsigned char *prev,
+                          size_t n_prev);
+/* Image::writeImageBMP(filename, x, y, w, h), imageWriter.h:472-488 */
+int or_update_bmp_rows(const char *path, const float *rgb, int W, int x, int y, int w, int h);
 
 #ifdef __cplusplus
 }

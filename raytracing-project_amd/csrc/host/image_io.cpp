@@ -11,7 +11,15 @@
 //     come out skewed exactly as the reference's do;
 //   * depth.bmp: grey = 1 - normalised depth, and the reference's inner loop
 //     runs over 3*w "pixels" per row (imageWriter.h:379-389), overwriting the
-//     following rows' start; reproduced by writing in the same order.
+//     following rows' start; reproduced by writing in the same order;
+//   * the three BMP writers fill one byte buffer that belongs to the Image
+//     (imageWriter.h:239) and blurred.bmp's padding loop writes three bytes
+//     early (imageWriter.h:456-458), so for widths whose rows need padding the
+//     last three bytes of every blurred.bmp row are whatever the previous
+//     writer (depth.bmp on the 'r' path) left there.  Image::imageC keeps that
+//     buffer between calls for the same reason;
+//   * the per-row update (imageWriter.h:472-488) seeks to 54 + (Y*w + x)*3,
+//     i.e. rows packed without the stride, into an existing file.
 #include <cstdio>
 #include <cstring>
 
@@ -44,7 +52,8 @@ void putHeaders(FILE* f, unsigned sizeField, int w, int h)
 
 inline int stride(int w) { return ((24 * w + 31) / 32) * 4; }
 
-bool writeColour(const char* filename, const float* img, int w, int h, unsigned sizeField, int padShift)
+bool writeColour(const char* filename, const float* img, int w, int h, unsigned sizeField, int padShift,
+                 std::vector<unsigned char>& bytes)
 {
     FILE* f = fopen(filename, "wb");
     if (!f) {
@@ -52,8 +61,8 @@ bool writeColour(const char* filename, const float* img, int w, int h, unsigned 
         return false;
     }
     putHeaders(f, sizeField, w, h);
-    const int                  rs = stride(w);
-    std::vector<unsigned char> bytes((size_t)rs * h + 8, 0);
+    const int rs = stride(w);
+    if (bytes.size() < (size_t)rs * h + 8) bytes.resize((size_t)rs * h + 8, 0);
     for (int y = 0; y < h; ++y) {
         unsigned char* row = bytes.data() + (size_t)y * rs;
         const float*   src = img + (size_t)y * w * 3;
@@ -89,14 +98,35 @@ bool Image::writeImagePPM(const char* filename) const
 
 bool Image::writeImageBMP(const char* filename) const
 {
-    return writeColour(filename, rgb.data(), width, height, (unsigned)(3 * width * height), 0);
+    return writeColour(filename, rgb.data(), width, height, (unsigned)(3 * width * height), 0, imageC);
+}
+
+// imageWriter.h:472-488: rows y..y+h-1, columns x..x+w-1 into the file writeImageBMP made
+bool Image::writeImageBMP(const char* filename, int x, int y, int w, int h) const
+{
+    FILE* f = fopen(filename, "r+b");
+    if (!f) return true; // the reference's fstream fails silently and still reports success
+    std::vector<unsigned char> row((size_t)w * 3);
+    for (int Y = y; Y < y + h; ++Y) {
+        for (int j = x; j < x + w; ++j) {
+            const float* src = rgb.data() + ((size_t)Y * width + j) * 3;
+            row[(size_t)(j - x) * 3] = quantize(src[2]);
+            row[(size_t)(j - x) * 3 + 1] = quantize(src[1]);
+            row[(size_t)(j - x) * 3 + 2] = quantize(src[0]);
+        }
+        fseek(f, 54 + ((long)Y * w + x) * 3, SEEK_SET);
+        fwrite(row.data(), 1, row.size(), f);
+    }
+    fclose(f);
+    return true;
 }
 
 bool Image::writeBlurredBMP(const char* filename) const
 {
     const int bw = width - 12, bh = height - 12;
     if (bw <= 0 || bh <= 0 || blurred.size() != (size_t)bw * bh * 3) return false;
-    return writeColour(filename, blurred.data(), bw, bh, (unsigned)(bw * bh), 3);
+    if (imageC.size() < (size_t)stride(width) * height + 8) imageC.resize((size_t)stride(width) * height + 8, 0);
+    return writeColour(filename, blurred.data(), bw, bh, (unsigned)(bw * bh), 3, imageC);
 }
 
 bool Image::writeDepthBMP(const char* filename) const
@@ -109,7 +139,8 @@ bool Image::writeDepthBMP(const char* filename) const
     putHeaders(f, (unsigned)(3 * width * height), width, height);
     const int                  rs = stride(width);
     const size_t               npx = (size_t)width * height;
-    std::vector<unsigned char> bytes((size_t)rs * height + (size_t)9 * width + 16, 0);
+    std::vector<unsigned char>& bytes = imageC;
+    if (bytes.size() < (size_t)rs * height + 8) bytes.resize((size_t)rs * height + 8, 0);
     for (int y = 0; y < height; ++y) {
         int i = 0;
         for (; i < width * 3; ++i) {

@@ -276,6 +276,26 @@ int rth_write_blurred_bmp(const char* path, const float* blurred, int w, int h)
     return asImage(nullptr, nullptr, blurred, w, h).writeBlurredBMP(path);
 }
 
+// The file sequence of the 'r' path on ONE Image, as main.cpp:325, 404-407 and 371-377 run
+// it: blank progress.bmp, one per-row update per row, result.ppm, result.bmp, depth.bmp
+// (depth_n = depth after the first normalisation), blurred.bmp (blurred = the blur's output).
+int rth_write_result_files(const char* out_dir, const float* rgb, const float* depth_n, const float* blurred,
+                           int w, int h)
+{
+    Image             blank(w, h);
+    const std::string dir = std::string(out_dir) + "/";
+    const std::string progress = dir + "progress.bmp";
+    bool              ok = blank.writeImageBMP(progress.c_str());
+    Image             im = asImage(rgb, depth_n, (w > 12 && h > 12) ? blurred : nullptr, w, h);
+    im.imageC = blank.imageC;
+    for (int y = 0; y < h; ++y) ok = im.writeImageBMP(progress.c_str(), 0, y, w, 1) && ok;
+    ok = im.writeImagePPM((dir + "result.ppm").c_str()) && ok;
+    ok = im.writeImageBMP((dir + "result.bmp").c_str()) && ok;
+    ok = im.writeDepthBMP((dir + "depth.bmp").c_str()) && ok;
+    if (w > 12 && h > 12) ok = im.writeBlurredBMP((dir + "blurred.bmp").c_str()) && ok;
+    return ok;
+}
+
 // init() + camera.sav + the 'r' path; returns seconds or < 0
 double rth_render_to_files(const char* obj_path, const char* camera_sav, int w, int h, int msaa,
                            const char* out_dir, int device, RtStats* stats)

@@ -72,10 +72,15 @@ void cameraCorners(const double modelview[16], int width, int height, float corn
 struct Image {
     int                width = 0, height = 0;
     std::vector<float> rgb, depth, blurred;
+    // imageWriter.h:239: the byte buffer the three BMP writers share; what one writer leaves
+    // in it shows through in the next file where that one skips bytes
+    mutable std::vector<unsigned char> imageC;
     Image() {}
     Image(int w, int h) : width(w), height(h), rgb((size_t)3 * w * h), depth((size_t)w * h) {}
     bool writeImagePPM(const char* filename) const;
     bool writeImageBMP(const char* filename) const;
+    // imageWriter.h:472: rewrites rows y..y+h-1, columns x..x+w-1 of an existing result.bmp
+    bool writeImageBMP(const char* filename, int x, int y, int w, int h) const;
     bool writeDepthBMP(const char* filename) const;   // expects normalised depth
     bool writeBlurredBMP(const char* filename) const; // expects `blurred` filled
 };

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librt_host.so")
 EXPORTS = ["rth_scene_load", "rth_scene_free", "rth_scene_desc", "rth_tree_depth",
            "rth_material_name", "rth_read_camera_sav", "rth_camera_corners", "rth_write_ppm",
            "rth_write_bmp", "rth_write_depth_bmp", "rth_write_blurred_bmp", "rth_render_to_files",
-           "rth_last_error", "rth_decode_png", "rth_render_to_files_focus"]
+           "rth_last_error", "rth_decode_png", "rth_render_to_files_focus", "rth_write_result_files"]
 
 _lib = None
 
@@ -42,6 +42,7 @@ def lib():
     L.rth_camera_corners.restype = None
     for n in ("rth_write_ppm", "rth_write_bmp", "rth_write_depth_bmp", "rth_write_blurred_bmp"):
         getattr(L, n).argtypes = [C.c_char_p, P, C.c_int, C.c_int]
+    L.rth_write_result_files.argtypes = [C.c_char_p, P, P, P, C.c_int, C.c_int]
     L.rth_render_to_files.restype = C.c_double
     L.rth_render_to_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                       C.c_int, C.POINTER(capi.RtStats)]
@@ -177,6 +178,18 @@ def write_depth_bmp(path, depth_n):
 
 def write_blurred_bmp(path, blurred):
     _write("rth_write_blurred_bmp", path, blurred, blurred.shape[1] + 12, blurred.shape[0] + 12)
+
+
+def write_result_files(out_dir, rgb, depth_n, blurred):
+    """progress.bmp (blank file + per-row updates), result.ppm, result.bmp, depth.bmp and
+    blurred.bmp written by one Image in the order of the reference's 'r' path."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    H, W = rgb.shape[:2]
+    dn = np.ascontiguousarray(depth_n, np.float32)
+    bl = np.ascontiguousarray(blurred, np.float32) if blurred is not None else None
+    if not lib().rth_write_result_files(os.fsencode(out_dir), rgb.ctypes.data, dn.ctypes.data,
+                                        bl.ctypes.data if bl is not None else None, W, H):
+        raise OSError(f"rth_write_result_files({out_dir}) failed")
 
 
 def render_to_files(obj_path, camera_sav, W, H, msaa, out_dir, device=0):

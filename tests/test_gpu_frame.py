@@ -161,16 +161,9 @@ def test_r_path_files_match_oracle_writers(P, oracle, tmp_path):
     s.set_lights(lights)
     s.settings.MSAA = msaa
     rgb, depth, _ = s.render(oracle.camera_corners(m, W, H), W, H, threads=8)
-    L = oracle.lib()
     ref = tmp_path / "ref"
     ref.mkdir()
-    L.or_write_ppm(str(ref / "result.ppm").encode(), rgb.reshape(-1), W, H)
-    L.or_write_bmp(str(ref / "result.bmp").encode(), rgb.reshape(-1), W, H)
-    dn = oracle.normalize_depth(depth)
-    L.or_write_depth_bmp(str(ref / "depth.bmp").encode(), None, dn.reshape(-1), W, H)
-    dn = oracle.normalize_depth(dn)
-    blur = oracle.blur(rgb, dn, threads=8)
-    L.or_write_blurred_bmp(str(ref / "blurred.bmp").encode(), blur.reshape(-1), W, H)
+    oracle.write_result_files(str(ref), rgb, depth, 0.0, threads=8)
     for f in ("result.ppm", "result.bmp", "depth.bmp", "blurred.bmp"):
         a = np.frombuffer((tmp_path / f).read_bytes(), np.uint8)
         b = np.frombuffer((ref / f).read_bytes(), np.uint8)
@@ -197,15 +190,10 @@ def test_focus_pick_then_r_path(P, oracle, tmp_path):
     _, min_t, tri = s.trace_rays(o[None], d[None])
     assert tri[0] >= 0 and focus == min_t[0] and 0 < focus < 1     # bit-equal depth of the picked point
     rgb, depth, _ = s.render(corners, W, H, threads=8)
-    L = oracle.lib()
     ref = tmp_path / "ref"
     ref.mkdir()
-    dn = oracle.normalize_depth(depth, focus)
-    L.or_write_depth_bmp(str(ref / "depth.bmp").encode(), None, dn.reshape(-1), W, H)
-    dn2 = oracle.normalize_depth(dn, focus)
+    dn, dn2, _ = oracle.write_result_files(str(ref), rgb, depth, focus, threads=8)
     assert not np.array_equal(dn, dn2)
-    blur = oracle.blur(rgb, dn2, threads=8)
-    L.or_write_blurred_bmp(str(ref / "blurred.bmp").encode(), blur.reshape(-1), W, H)
     for f in ("depth.bmp", "blurred.bmp"):
         a = np.frombuffer((tmp_path / f).read_bytes(), np.uint8)
         b = np.frombuffer((ref / f).read_bytes(), np.uint8)
