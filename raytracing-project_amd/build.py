@@ -35,8 +35,9 @@ def hipcc():
 
 def build_hip(force=False):
     out = os.path.join(CSRC, "librt_hip.so")
-    src = [os.path.join(CSRC, "rt_api.hip"), os.path.join(CSRC, "rt_device.h"),
-           os.path.join(ROOT, "include", "rt_hip.h")]
+    src = [os.path.join(CSRC, "rt_api.hip")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "rt_hip.h")]
     if force or _newer(out, src):
         subprocess.check_call([hipcc(), *HIP_FLAGS, "-shared", src[0], "-o", out])
     return out

@@ -147,6 +147,11 @@ bool readRtex(const std::string& path, Texture& t)
         ok = w > 0 && h > 0 && w <= 16384 && h <= 16384;
     }
     std::vector<unsigned char> z;
+    if (ok) { // the compressed length the header states has to fit the file
+        const long at = ftell(f);
+        ok = fseek(f, 0, SEEK_END) == 0 && ftell(f) >= at && (unsigned long)(ftell(f) - at) >= zl &&
+             fseek(f, at, SEEK_SET) == 0;
+    }
     if (ok) {
         z.resize(zl);
         ok = fread(z.data(), 1, zl, f) == zl;
@@ -221,9 +226,10 @@ bool Mesh::loadMesh(const char* filename, bool /*randomizeTriangulation*/, bool 
                     const char* q = p;
                     while (*q && *q != '/' && *q != ' ' && *q != '\n' && *q != '\r') ++q;
                     if (q != p) {
-                        const int v = atoi(std::string(p, q).c_str()) - 1;
-                        if (field == 0) vi.push_back(v);
-                        else if (field == 1) ti.push_back(v);
+                        // 1-based; a negative index counts back from the entries read so far
+                        const int raw = atoi(std::string(p, q).c_str());
+                        if (field == 0) vi.push_back(raw < 0 ? (int)vertexCount() + raw : raw - 1);
+                        else if (field == 1) ti.push_back(raw < 0 ? (int)(texcoords.size() / 3) + raw : raw - 1);
                     }
                     ++field;
                     p = q;
@@ -241,6 +247,31 @@ bool Mesh::loadMesh(const char* filename, bool /*randomizeTriangulation*/, bool 
         }
     }
     fclose(in);
+
+    // The reference indexes its vertex and texcoord arrays with whatever the file says
+    // (mesh.cpp:298-325).  Here a face that names a vertex the file does not have is dropped
+    // and a texcoord index outside the list reads entry 0, before anything indexes with them.
+    {
+        const int nv = (int)vertexCount(), ntc = (int)(texcoords.size() / 3);
+        size_t    kept = 0, dropped = 0;
+        for (size_t t = 0; t < tri_material.size(); ++t) {
+            bool ok = true;
+            for (int j = 0; j < 3; ++j) ok = ok && tri_vertex[3 * t + j] >= 0 && tri_vertex[3 * t + j] < nv;
+            if (!ok) {
+                ++dropped;
+                continue;
+            }
+            for (int j = 0; j < 3; ++j) {
+                const int tc = tri_texcoord[3 * t + j];
+                tri_vertex[3 * kept + j] = tri_vertex[3 * t + j];
+                tri_texcoord[3 * kept + j] = (tc >= 0 && tc < ntc) ? tc : 0;
+            }
+            tri_material[kept++] = tri_material[t];
+        }
+        tri_vertex.resize(3 * kept), tri_texcoord.resize(3 * kept), tri_material.resize(kept);
+        if (dropped)
+            fprintf(stderr, "TriMesh::LOAD: %zu faces name a vertex outside 1..%d. Ignoring them\n", dropped, nv);
+    }
 
     // every material tries to open its (possibly inherited) texture, mesh.cpp:346-348
     for (auto& pm : file_mats) {

@@ -823,6 +823,13 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         }
     }
     if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
+    if (lists.empty()) { // a description without a tree: one empty leaf, every ray misses
+        lists.emplace_back();
+        new_left.push_back(-1);
+        axis_of.push_back(0);
+        split_of.push_back(0.0f);
+        depth_of.push_back(0);
+    }
     std::vector<DNode>  nodes(lists.size());
     std::vector<float4> slots;
     for (size_t k = 0; k < lists.size(); ++k) {

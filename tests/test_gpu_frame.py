@@ -275,6 +275,29 @@ def test_bad_arguments_are_rejected(P):
     assert np.isfinite(rgb).all()
 
 
+def test_scene_without_a_tree_renders_background(P):
+    """A description with no KD nodes (only the raw C ABI can make one: the host builder always
+    emits a root) is given one empty leaf: every ray misses, frames are background, nothing hangs."""
+    hs, _, m, lights = _host_gpu(P, "ball")
+    a = hs.arrays()
+    none_i, none_f = np.zeros(0, np.int32), np.zeros((0, 6), np.float32)
+    for tris in (True, False):
+        gs = P.capi.Scene(a["vertex_pos"], a["vertex_normal"],
+                          a["tri_vertex"] if tris else np.zeros((0, 3), np.int32),
+                          a["tri_texcoord"] if tris else np.zeros((0, 3), np.int32),
+                          a["tri_material"] if tris else none_i, a["texcoords"], a["materials"],
+                          a["textures"], none_f, none_i, none_i, none_i, none_i, none_i)
+        assert gs.info()["n_nodes"] == 1
+        for msaa in (1, 4):
+            rgb, depth, tri, st = gs.render(P.host.camera_corners(m, 64, 48), lights, P.capi.default_params(64, 48, msaa))
+            assert (tri == -1).all() and (depth == FLT_MAX).all()
+            assert (rgb == np.float32([0.2, 0.5, 1.0])).all() and st.rays_shadow == 0
+        t, _, _, _, _ = gs.check_hits([[0, 1.6, 3.6]], [[0, 0.45, 0]])
+        assert t[0] == -1
+        c, mt, _, _ = gs.trace_rays([[0, 1.6, 3.6]], [[0, 0.45, 0]], lights)
+        assert np.array_equal(c[0], np.float32([0.2, 0.5, 1.0])) and mt[0] == FLT_MAX
+
+
 def test_trace_rays_k_and_prev_ni(P, oracle):
     """performRayTracing's k and prev_Ni arguments (raytracing.cpp:61,166-175)."""
     s = oracle.Scene.load(os.path.join(SCENES, "refractionballs.obj"))

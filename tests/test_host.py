@@ -54,6 +54,33 @@ def test_host_scene_equals_oracle(P, oracle, name):
         walk(nd["bounds"], nd["left"], nd["right"], nd["tri_off"], nd["tri_cnt"], nd["tris"])
 
 
+def test_malformed_and_relative_obj_indices(P, tmp_path):
+    """Faces naming vertices the file does not have are dropped, negative indices count back from
+    the entries read so far, texcoord indices outside the list read entry 0 - before the normals
+    or the KD build index anything with them.  A .rtex header may not claim more bytes than the
+    file holds."""
+    obj = tmp_path / "bad.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0.5 0.5\n"
+                   "f 1 2 3\n"            # fine
+                   "f -3 -2 -1\n"         # relative: vertices 2 3 4
+                   "f 1 2 9\n"            # vertex 9 does not exist
+                   "f 0 1 2\n"            # index 0 is not valid in OBJ
+                   "f 1/7 2/1 3/-1\n"     # texcoord 7 does not exist, -1 is the last one
+                   "f 1 2 1000000\n")
+    hs = P.host.HostScene(str(obj))
+    a = hs.arrays()
+    assert a["tri_vertex"].tolist() == [[0, 1, 2], [1, 2, 3], [0, 1, 2]]
+    assert a["tri_texcoord"].tolist() == [[0, 0, 0], [0, 0, 0], [0, 0, 0]]
+    assert np.isfinite(a["vertex_normal"]).all() and len(a["node_bounds"]) >= 1
+    tex = tmp_path / "t.png.rtex"
+    tex.write_bytes(b"RTEX" + np.array([4, 4, 1 << 30], np.uint32).tobytes() + b"xx")
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd t.png\n\n")
+    obj2 = tmp_path / "tex.obj"
+    obj2.write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    a2 = P.host.HostScene(str(obj2)).arrays()
+    assert len(a2["textures"]) == 0 and a2["materials"][1, 10] == -1
+
+
 def test_host_missing_scene(P):
     with pytest.raises(FileNotFoundError):
         P.host.HostScene(os.path.join(SCENES, "does_not_exist.obj"))
