@@ -199,6 +199,18 @@ int rt_normalize_depth(int device, int64_t n, float focus_depth, float *depth);
 int rt_normalize_depth_device(int device, int64_t n, float focus_depth, float *d_depth,
                               void *stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate device
+ * memory - code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc: rt_normalize_depth_device with its scratch (the per-block
+ * partial minima and maxima, 8 KB) in a fixed device array of the library
+ * instead of the stream's memory pool.  Calls no hipMalloc / hipFree or any
+ * other allocating routine.  n may not exceed RT_NOALLOC_MAX_DEPTH_VALUES.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race; calls on one stream are safe. */
+#define RT_NOALLOC_MAX_DEPTH_VALUES ((int64_t)1 << 28) /* a 16384 x 16384 frame */
+int rt_normalize_depth_device_noalloc(int device, int64_t n, float focus_depth, float *d_depth,
+                                      void *stream);
+
 /* Image::blurrAllLines (imageWriter.h:137-237): depth-dependent 13x13 blur of
  * the float image; depth_n is the normalised depth.  out is
  * (width-12)*(height-12)*3 floats. */

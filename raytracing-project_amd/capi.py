@@ -79,7 +79,7 @@ class RtSceneInfo(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device",
-    "rt_normalize_depth", "rt_normalize_depth_device", "rt_dof_blur", "rt_dof_blur_device",
+    "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
     "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
 ]
 
@@ -123,6 +123,7 @@ def lib():
                                          C.POINTER(RtStats)]
     L.rt_normalize_depth.argtypes = [C.c_int, I64, F, P]
     L.rt_normalize_depth_device.argtypes = [C.c_int, I64, F, P, P]
+    L.rt_normalize_depth_device_noalloc.argtypes = [C.c_int, I64, F, P, P]
     L.rt_dof_blur.argtypes = [C.c_int, I32, I32, F, P, P, P]
     L.rt_dof_blur_device.argtypes = [C.c_int, I32, I32, F, P, P, P, P]
     L.rt_quantize.argtypes = [C.c_int, I64, P, P]

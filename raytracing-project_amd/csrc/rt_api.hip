@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1572,6 +1573,50 @@ extern "C" int rt_normalize_depth_device(int device, int64_t n, float focus, flo
     rc = normalize_depth_impl(n, focus, d_depth, d_part, (hipStream_t)stream);
     (void)hipFreeAsync(d_part, (hipStream_t)stream);
     return rc;
+}
+
+// ---- the entry point that allocates nothing ----
+// Partial minima / maxima of rt_normalize_depth_device_noalloc: the same 2 x RANGE_BLOCKS floats
+// rt_normalize_depth_device takes from the stream's memory pool, here in a file-scope device
+// array.  Every GPU the library runs on holds its own copy (8 KB) until the process ends.  The
+// array's name is a host-side stand-in, not a device address: host code uses the per-device
+// pointer hipGetSymbolAddress returns, looked up once per device with that device current.
+static __device__ __align__(256) float scratch[2 * RANGE_BLOCKS];
+#define RT_NOALLOC_MAX_DEVICES 64
+static float*     g_scratch_ptr[RT_NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_device(int device, float** out)
+{
+    if (device >= RT_NOALLOC_MAX_DEVICES)
+        return fail(RT_ERR_UNSUPPORTED, "rt_normalize_depth_device_noalloc: device %d beyond the %d supported", device,
+                    RT_NOALLOC_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) { // `device` is current: check_device() set it
+        float* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "rt_normalize_depth_device_noalloc: no address for the scratch array");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+extern "C" int rt_normalize_depth_device_noalloc(int device, int64_t n, float focus, float* d_depth,
+                                                 void* stream)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n < 0) return fail(RT_ERR_INVALID, "rt_normalize_depth_device_noalloc: negative n");
+    if (n > RT_NOALLOC_MAX_DEPTH_VALUES)
+        return fail(RT_ERR_INVALID, "rt_normalize_depth_device_noalloc: n = %lld exceeds the maximum of %lld values",
+                    (long long)n, (long long)RT_NOALLOC_MAX_DEPTH_VALUES);
+    if (n == 0) return RT_OK;
+    if (!d_depth) return fail(RT_ERR_INVALID, "rt_normalize_depth_device_noalloc: null depth");
+    float* part = nullptr;
+    if ((rc = scratch_for_device(device, &part))) return rc;
+    // both kernels write every partial they later read (nb blocks each), nothing has to start at zero
+    return normalize_depth_impl(n, focus, d_depth, part, (hipStream_t)stream);
 }
 
 extern "C" int rt_normalize_depth(int device, int64_t n, float focus, float* depth)
