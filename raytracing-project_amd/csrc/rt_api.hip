@@ -1534,6 +1534,21 @@ extern "C" int rt_render_frame(RtScene* s, const float camera[24], const float* 
     return RT_OK;
 }
 
+#ifdef WF_TIMELINE
+// diagnostic builds only: copy out (and clear) the region time stamps of k_wf_pipeline
+extern "C" int rt_debug_timeline(unsigned long long* out, int64_t n_regions, int clear)
+{
+    if (n_regions > WF_TL_REGIONS) n_regions = WF_TL_REGIONS;
+    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n_regions * 16 * 8));
+    if (clear) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_timeline)));
+        HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * WF_TL_REGIONS * 16));
+    }
+    return RT_OK;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // post-process
 // ---------------------------------------------------------------------------

@@ -764,6 +764,13 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
 // ---------------------------------------------------------------------------
 // the whole frame part in one persistent launch
 // ---------------------------------------------------------------------------
+// Measured with a -DWF_TIMELINE build (tools/timeline.py): the median region of a 4K MSAA4
+// frame of final.obj takes 0.25 ms under load, the slowest 3 ms; the blocks stay busy until 0.9 ms
+// before the end of a 11.9 ms launch (1.0 of 2.6 ms for an eighth of the frame).  Tried against
+// that tail and not kept: raising the wave priority (s_setprio) with the level of the recursion
+// (no change at all); postponing regions whose first trace hits no material that spawns rays, so
+// that the others start earlier (13.2 vs 12.0 ms, 2.73 vs 2.56 ms: in this scene nearly every
+// region touches a mirror, the bookkeeping only costs).
 // What ends the launch is the longest region, not the order: 64 pixels of mirror facing
 // mirror run five levels of long rays, 1.5-2 ms however the rest is scheduled.  Tried and not
 // kept: regions handed out by descending cost estimate from a first pass (the second launch
@@ -850,6 +857,15 @@ __device__ __forceinline__ void wf_trace_merged(const DScene& S, const DParams& 
 #ifndef WF_PIPE_WAVES
 #define WF_PIPE_WAVES 7
 #endif
+#ifdef WF_TIMELINE
+// Diagnostic builds only (-DWF_TIMELINE, read by tools/timeline.py): 16 time stamps of the 100 MHz
+// wall clock per region - start, end of each stage - and the block that ran it.
+#define WF_TL_REGIONS 140000
+__device__ unsigned long long g_timeline[WF_TL_REGIONS * 16];
+#define WF_TL(slot) do { if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define WF_TL(slot) do { } while (0)
+#endif
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
 k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* rgb, float* depth, int* tri,
@@ -867,6 +883,10 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         const int r = sh.region;
         if (r >= B.G) break;
         const size_t base = (size_t)r * B.R;
+        WF_TL(0);
+#ifdef WF_TIMELINE
+        if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + 15] = blockIdx.x;
+#endif
         for (int j = threadIdx.x; j < B.S * P.msaa; j += WF_BLOCK) { // this region's colour sums
             const size_t k = (size_t)r * B.S * P.msaa + j;
             B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
@@ -876,6 +896,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         wf_trace_region<false, COUNT>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base,
                                       B.rays[0].hits, nullptr, stk, n_tests, n_nodes, n_closest);
         __syncthreads();
+        WF_TL(1);
         int q = 0;
         if (P.msaa > 1) {
             wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, r, &sh);
@@ -885,6 +906,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
                                           B.rays[1].hits, nullptr, stk, n_tests, n_nodes, n_closest);
             __syncthreads();
         }
+        WF_TL(2);
         // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
         if (B.rays[q].cnt[r] > 0) {
             wf_shade_region(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh);
@@ -894,18 +916,22 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
                 const int    n_out = out.cnt[r];
                 wf_trace_merged<COUNT>(S, P, B, out, n_out, r, stk, n_tests, n_nodes, n_closest, n_shadow);
                 __syncthreads();
+                WF_TL(3 + 2 * level);
                 wf_resolve_region(S, P, B, in, r);
                 if (n_out == 0) break;
                 __syncthreads(); // resolve still reads the queue the next shade writes its children to
                 wf_shade_region(S, P, B, out, in, r, &sh);
                 __syncthreads();
+                WF_TL(4 + 2 * level);
             }
             __syncthreads();
         }
+        WF_TL(13);
         for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
             const int i = r * B.S + j;
             if (i < n) wf_finalize_slot(P, B, slot0, i, centre_hit, rgb, depth, tri);
         }
+        WF_TL(14);
     }
     for (int s = 32; s > 0; s >>= 1) {
         n_tests += __shfl_down(n_tests, s);

@@ -1,0 +1,72 @@
+"""Region timeline of k_wf_pipeline from a -DWF_TIMELINE build of the library:
+  RT_HIP_LIB=exp/librt_tl.so [WORLD=8 RANK=0] python tools/timeline.py final 3840 2160 4
+Prints how many blocks work over time, the distribution of region durations and the share of
+each stage."""
+import ctypes as C
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("raytracing-project_amd")
+capi, host = pkg.capi, pkg.host
+import torch
+name, W, H, msaa = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+hs = host.HostScene(os.path.join(ROOT, "scenes", name + ".obj"))
+gs = hs.to_gpu(0)
+m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
+corners = host.camera_corners(m, W, H)
+p = capi.default_params(W, H, msaa)
+if os.environ.get("WORLD"):
+    p.tile_w = p.tile_h = 32; p.world = int(os.environ["WORLD"]); p.rank = int(os.environ.get("RANK", "0"))
+d_rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+d_depth = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+L = capi.lib()
+L.rt_debug_timeline.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+for _ in range(3):
+    gs.render_device(corners, lights, p, d_rgb.data_ptr(), d_depth.data_ptr(), 0, 0, False)
+torch.cuda.synchronize()
+L.rt_debug_timeline(None, 0, 1)
+gs.set_timing(True)
+gs.render_device(corners, lights, p, d_rgb.data_ptr(), d_depth.data_ptr(), 0, 0, False)
+torch.cuda.synchronize()
+kt = gs.collect_timing()
+NR = 140000
+tl = np.zeros((NR, 16), np.uint64)
+L.rt_debug_timeline(tl.ctypes.data, NR, 0)
+tl = tl[tl[:, 14] > 0].astype(np.int64)
+t0 = tl[:, 0].min()
+start, end = (tl[:, 0] - t0) / 100.0, (tl[:, 14] - t0) / 100.0      # microseconds
+dur = end - start
+total = end.max()
+print(f"{name} {W}x{H} msaa{msaa} world {p.world}: launch {kt.frame_ms:.3f} ms; {len(tl)} regions, "
+      f"{len(np.unique(tl[:, 15]))} blocks, span {total/1e3:.3f} ms")
+print("region duration us: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" %
+      (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+# blocks busy over time
+edges = np.linspace(0, total, 41)
+ev = np.concatenate([np.stack([start, np.ones_like(start)], 1), np.stack([end, -np.ones_like(end)], 1)])
+ev = ev[np.argsort(ev[:, 0])]
+busy = np.cumsum(ev[:, 1])
+for k in range(40):
+    sel = (ev[:, 0] >= edges[k]) & (ev[:, 0] < edges[k + 1])
+    print(f"  t={edges[k]/1e3:6.2f} ms  busy blocks ~{busy[sel].mean() if sel.any() else float('nan'):7.0f}  regions started {int(((start >= edges[k]) & (start < edges[k+1])).sum())}")
+# stage shares (per region: 0 start, 1 centre traced, 2 samples traced, 3+2l trace(l), 4+2l shade(l+1), 13 levels done, 14 end)
+names = ["gen+centre trace", "msaa emit+trace"] + [f"L{l} {s}" for l in range(5) for s in ("shade+trace", "resolve+shade")]
+seg = np.zeros(len(names))
+prev = tl[:, 0].copy()
+cols = [1, 2] + [c for l in range(5) for c in (3 + 2 * l, 4 + 2 * l)]
+for i, c in enumerate(cols):
+    cur = tl[:, c]
+    ok = cur > 0
+    seg[i] = (cur[ok] - prev[ok]).clip(min=0).sum()
+    prev = np.where(ok, cur, prev)
+tail = (tl[:, 14] - prev).sum()
+tot = seg.sum() + tail
+for n_, v in zip(names, seg):
+    print(f"  {n_:20s} {100*v/tot:5.1f}%")
+print(f"  {'last resolve+finalize':20s} {100*tail/tot:5.1f}%")
+# the longest regions
+idx = np.argsort(-dur)[:8]
+for i in idx:
+    print(f"  long region: start {start[i]/1e3:.2f} ms, dur {dur[i]:.0f} us, stages " +
+          " ".join(str(int((tl[i, c] - tl[i, 0]) / 100)) if tl[i, c] else "-" for c in range(1, 15)))
