@@ -177,11 +177,10 @@ def main():
                                                  state["deal"])
             if rank == 0:
                 sl["ev"][0].record()
-                # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416)
-                for _ in range(2):
-                    capi.check(L.rt_normalize_depth_device(local, W * H, p.focusDepth, d_depth, C.c_void_p(stream)))
-                capi.check(L.rt_dof_blur_device(local, W, H, p.depthPower, d_rgb, d_depth,
-                                                C.c_void_p(sl["blurred"].data_ptr()), C.c_void_p(stream)))
+                # writeDepthBMP and writeBlurredBMP each normalise (imageWriter.h:352,416): the first
+                # in place, the second as the blur reads the plane
+                capi.check(L.rt_postprocess_device(local, W, H, p.focusDepth, p.depthPower, d_rgb, d_depth,
+                                                   C.c_void_p(sl["blurred"].data_ptr()), C.c_void_p(stream)))
                 sl["ev"][1].record()
         return st
 

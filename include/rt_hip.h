@@ -219,6 +219,15 @@ int rt_dof_blur(int device, int32_t width, int32_t height, float depth_power, co
 int rt_dof_blur_device(int device, int32_t width, int32_t height, float depth_power,
                        const float *d_rgb, const float *d_depth_n, float *d_out, void *stream);
 
+/* The arithmetic of writeDepthBMP + writeBlurredBMP (imageWriter.h:352, 416-418) on a frame in
+ * device memory, in one call: d_depth (width*height, FLT_MAX = miss) is normalised in place -
+ * afterwards it is the plane depth.bmp shows - and d_blurred (may be NULL: no blur) receives
+ * the (width-12)*(height-12)*3 floats of blurred.bmp, computed from the plane normalised a second
+ * time as the reference does; that second normalisation is applied as the blur reads the plane,
+ * it is not stored.  Same values as rt_normalize_depth_device twice + rt_dof_blur_device. */
+int rt_postprocess_device(int device, int32_t width, int32_t height, float focus_depth, float depth_power,
+                          const float *d_rgb, float *d_depth, float *d_blurred, void *stream);
+
 /* (unsigned char)(v * 255.0f) of imageWriter.h:270,322-324 for n floats. */
 int rt_quantize(int device, int64_t n, const float *v, uint8_t *out);
 

@@ -80,7 +80,7 @@ EXPORTS = [
     "rt_default_params", "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device",
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
-    "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
+    "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def lib():
     L.rt_normalize_depth_device_noalloc.argtypes = [C.c_int, I64, F, P, P]
     L.rt_dof_blur.argtypes = [C.c_int, I32, I32, F, P, P, P]
     L.rt_dof_blur_device.argtypes = [C.c_int, I32, I32, F, P, P, P, P]
+    L.rt_postprocess_device.argtypes = [C.c_int, I32, I32, F, F, P, P, P, P]
     L.rt_quantize.argtypes = [C.c_int, I64, P, P]
     L.rt_tile_pixels.argtypes = [C.POINTER(RtParams), I32]
     L.rt_tile_pixels.restype = I64

@@ -271,23 +271,54 @@ __global__ void k_depth_range_partial(const float* __restrict__ depth, long long
     if (threadIdx.x == 0) part_lo[blockIdx.x] = s_lo[0], part_hi[blockIdx.x] = s_hi[0];
 }
 
-// imageWriter.h:124-135; one block reduces the partials, every block normalises
-__global__ void k_depth_normalize(float* depth, long long n, const float* __restrict__ part_lo,
-                                  const float* __restrict__ part_hi, int n_part, float focus)
+// imageWriter.h:125-127: the partial extremes -> denom = max(|lowest - f|, |highest - f|)
+__global__ void __launch_bounds__(256)
+k_depth_denominator(const float* __restrict__ part_lo, const float* __restrict__ part_hi, int n_part,
+                    float focus, float* denom)
 {
-    __shared__ float s_denom;
-    if (threadIdx.x == 0) {
-        float lo = RT_FLT_MAX, hi = 0.0f;
-        for (int i = 0; i < n_part; ++i) lo = fminf(lo, part_lo[i]), hi = fmaxf(hi, part_hi[i]);
-        s_denom = fmaxf(fabsf(lo - focus), fabsf(hi - focus));
-    }
+    __shared__ float s_lo[256], s_hi[256];
+    float            lo = RT_FLT_MAX, hi = 0.0f;
+    for (int i = threadIdx.x; i < n_part; i += 256) lo = fminf(lo, part_lo[i]), hi = fmaxf(hi, part_hi[i]);
+    s_lo[threadIdx.x] = lo, s_hi[threadIdx.x] = hi;
     __syncthreads();
-    const float denom = s_denom;
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
+            s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *denom = fmaxf(fabsf(s_lo[0] - focus), fabsf(s_hi[0] - focus));
+}
+
+// imageWriter.h:129-134.  With part_lo != nullptr the block also reduces the extremes of what it
+// writes (getDepthRange of the normalised plane, for the second normalisation of the 'r' path).
+__global__ void __launch_bounds__(256)
+k_depth_normalize(float* depth, long long n, const float* __restrict__ denom_p, float focus, float* part_lo,
+                  float* part_hi)
+{
+    __shared__ float s_lo[256], s_hi[256];
+    const float      denom = *denom_p;
+    float            lo = RT_FLT_MAX, hi = 0.0f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const float v = depth[i];
-        depth[i] = (v != RT_FLT_MAX) ? __fdiv_rn(fabsf(v - focus), denom) : 0.0f;
+        const float w = (v != RT_FLT_MAX) ? __fdiv_rn(fabsf(v - focus), denom) : 0.0f;
+        depth[i] = w;
+        lo = fminf(lo, w);
+        if (w != RT_FLT_MAX) hi = fmaxf(hi, w);
     }
+    if (!part_lo) return;
+    s_lo[threadIdx.x] = lo, s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
+            s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_lo[blockIdx.x] = s_lo[0], part_hi[blockIdx.x] = s_hi[0];
 }
 
 // ---- depth-of-field blur, imageWriter.h:137-231 ----
@@ -322,7 +353,7 @@ __device__ __forceinline__ float dof_pow_e(float x)
 
 __global__ void __launch_bounds__(DOF_BLOCK)
 k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int W, int H,
-           float depthPower, float* out)
+           float depthPower, float* out, const float* __restrict__ denom2, float focus)
 {
     __shared__ float4 s_px[DOF_LH * DOF_LW];
     const int bw = W - 12, bh = H - 12;
@@ -338,7 +369,10 @@ k_dof_blur(const float* __restrict__ rgb, const float* __restrict__ depthN, int 
     const int tx = threadIdx.x % DOF_TW, ty = threadIdx.x / DOF_TW;
     const int ox = x0 + tx, oy = y0 + ty;
     if (ox >= bw || oy >= bh) return;
-    float I = 1.0f - depthN[(size_t)(oy + 6) * W + ox + 6];
+    float dn = depthN[(size_t)(oy + 6) * W + ox + 6];
+    if (denom2) // the plane is normalised once; imageWriter.h:416 normalises it again before the blur
+        dn = (dn != RT_FLT_MAX) ? __fdiv_rn(fabsf(dn - focus), *denom2) : 0.0f;
+    float I = 1.0f - dn;
     I *= I;
     float* o = out + 3 * ((size_t)oy * bw + ox);
     if (I >= 1.0f) { // identity kernel
@@ -1563,14 +1597,27 @@ static int check_device(int device)
     return RT_OK;
 }
 
-static int normalize_depth_impl(int64_t n, float focus, float* d_depth, float* d_part, hipStream_t st)
+// Scratch layout of the depth passes: [0, RANGE_BLOCKS) partial minima, [RANGE_BLOCKS, 2 RANGE_BLOCKS)
+// partial maxima, then the two denominators.
+#define DEPTH_SCRATCH_FLOATS (2 * RANGE_BLOCKS + 64)
+
+static int depth_blocks(int64_t n) { return (int)std::min<long long>(RANGE_BLOCKS, (n + 255) / 256); }
+
+// One normalisation.  again: also leave the denominator of a second normalisation of the
+// result in d_part[2 * RANGE_BLOCKS + 1].
+static int normalize_depth_impl(int64_t n, float focus, float* d_depth, float* d_part, hipStream_t st,
+                                bool again = false)
 {
-    const int nb = (int)std::min<long long>(RANGE_BLOCKS, (n + 255) / 256);
-    hipLaunchKernelGGL(k_depth_range_partial, dim3(nb), dim3(256), 0, st, (const float*)d_depth,
-                       (long long)n, d_part, d_part + RANGE_BLOCKS);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_depth_normalize, dim3(nb), dim3(256), 0, st, d_depth, (long long)n,
-                       (const float*)d_part, (const float*)(d_part + RANGE_BLOCKS), nb, focus);
+    const int nb = depth_blocks(n);
+    float*    lo = d_part, *hi = d_part + RANGE_BLOCKS, *denom = d_part + 2 * RANGE_BLOCKS;
+    hipLaunchKernelGGL(k_depth_range_partial, dim3(nb), dim3(256), 0, st, (const float*)d_depth, (long long)n, lo, hi);
+    hipLaunchKernelGGL(k_depth_denominator, dim3(1), dim3(256), 0, st, (const float*)lo, (const float*)hi, nb, focus,
+                       denom);
+    hipLaunchKernelGGL(k_depth_normalize, dim3(nb), dim3(256), 0, st, d_depth, (long long)n, (const float*)denom,
+                       focus, again ? lo : (float*)nullptr, again ? hi : (float*)nullptr);
+    if (again)
+        hipLaunchKernelGGL(k_depth_denominator, dim3(1), dim3(256), 0, st, (const float*)lo, (const float*)hi, nb,
+                           focus, denom + 1);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -1584,19 +1631,20 @@ extern "C" int rt_normalize_depth_device(int device, int64_t n, float focus, flo
     if (n == 0) return RT_OK;
     if (!d_depth) return fail(RT_ERR_INVALID, "rt_normalize_depth: null depth");
     float* d_part = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&d_part, 2 * RANGE_BLOCKS * sizeof(float), (hipStream_t)stream));
+    HIP_TRY(hipMallocAsync((void**)&d_part, DEPTH_SCRATCH_FLOATS * sizeof(float), (hipStream_t)stream));
     rc = normalize_depth_impl(n, focus, d_depth, d_part, (hipStream_t)stream);
     (void)hipFreeAsync(d_part, (hipStream_t)stream);
     return rc;
 }
 
 // ---- the entry point that allocates nothing ----
-// Partial minima / maxima of rt_normalize_depth_device_noalloc: the same 2 x RANGE_BLOCKS floats
-// rt_normalize_depth_device takes from the stream's memory pool, here in a file-scope device
-// array.  Every GPU the library runs on holds its own copy (8 KB) until the process ends.  The
+// Partial minima / maxima and the denominator of rt_normalize_depth_device_noalloc: the same
+// DEPTH_SCRATCH_FLOATS floats rt_normalize_depth_device takes from the stream's memory pool, here
+// in a file-scope device array.  Every GPU the library runs on holds its own copy (8.25 KB) until
+// the process ends.  The
 // array's name is a host-side stand-in, not a device address: host code uses the per-device
 // pointer hipGetSymbolAddress returns, looked up once per device with that device current.
-static __device__ __align__(256) float scratch[2 * RANGE_BLOCKS];
+static __device__ __align__(256) float scratch[DEPTH_SCRATCH_FLOATS];
 #define RT_NOALLOC_MAX_DEVICES 64
 static float*     g_scratch_ptr[RT_NOALLOC_MAX_DEVICES];
 static std::mutex g_scratch_mutex;
@@ -1642,7 +1690,7 @@ extern "C" int rt_normalize_depth(int device, int64_t n, float focus, float* dep
     if (n == 0) return RT_OK;
     if (!depth) return fail(RT_ERR_INVALID, "rt_normalize_depth: null depth");
     DevBuf d, part;
-    if ((rc = d.alloc(4 * n)) || (rc = part.alloc(2 * RANGE_BLOCKS * sizeof(float)))) return rc;
+    if ((rc = d.alloc(4 * n)) || (rc = part.alloc(DEPTH_SCRATCH_FLOATS * sizeof(float)))) return rc;
     HIP_TRY(hipMemcpy(d.p, depth, 4 * n, hipMemcpyHostToDevice));
     if ((rc = normalize_depth_impl(n, focus, (float*)d.p, (float*)part.p, 0))) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1661,9 +1709,34 @@ extern "C" int rt_dof_blur_device(int device, int32_t W, int32_t H, float depth_
     if (!d_rgb || !d_depth_n || !d_out) return fail(RT_ERR_INVALID, "rt_dof_blur: null argument");
     const unsigned n_blocks = (unsigned)(((W - 12 + DOF_TW - 1) / DOF_TW) * ((H - 12 + DOF_TH - 1) / DOF_TH));
     hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, (hipStream_t)stream, d_rgb,
-                       d_depth_n, (int)W, (int)H, depth_power, d_out);
+                       d_depth_n, (int)W, (int)H, depth_power, d_out, (const float*)nullptr, 0.0f);
     HIP_TRY(hipGetLastError());
     return RT_OK;
+}
+
+extern "C" int rt_postprocess_device(int device, int32_t W, int32_t H, float focus, float depth_power,
+                                     const float* d_rgb, float* d_depth, float* d_blurred, void* stream_)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (W < 2 || H < 2 || W > 32768 || H > 32768)
+        return fail(RT_ERR_INVALID, "rt_postprocess: frame size %dx%d out of range (2..32768)", W, H);
+    if (!d_depth) return fail(RT_ERR_INVALID, "rt_postprocess: null depth");
+    const bool blur = d_blurred != nullptr;
+    if (blur && (W < 13 || H < 13)) return fail(RT_ERR_INVALID, "rt_postprocess: frame %dx%d must be at least 13x13 for the blur", W, H);
+    if (blur && !d_rgb) return fail(RT_ERR_INVALID, "rt_postprocess: null rgb");
+    hipStream_t st = (hipStream_t)stream_;
+    float*      d_part = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_part, DEPTH_SCRATCH_FLOATS * sizeof(float), st));
+    rc = normalize_depth_impl((int64_t)W * H, focus, d_depth, d_part, st, blur);
+    if (rc == RT_OK && blur) {
+        const unsigned n_blocks = (unsigned)(((W - 12 + DOF_TW - 1) / DOF_TW) * ((H - 12 + DOF_TH - 1) / DOF_TH));
+        hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, st, d_rgb, (const float*)d_depth, (int)W,
+                           (int)H, depth_power, d_blurred, (const float*)(d_part + 2 * RANGE_BLOCKS + 1), focus);
+        if (hipGetLastError() != hipSuccess) rc = fail(RT_ERR_HIP, "rt_postprocess: blur launch failed");
+    }
+    (void)hipFreeAsync(d_part, st);
+    return rc;
 }
 
 extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, const float* rgb,

@@ -242,6 +242,32 @@ def test_full_size_frames_against_sparse_fixture(P, oracle, key):
         assert 0.4 * cfg["frame"]["rays_shadow"] <= st.rays_shadow <= cfg["frame"]["rays_shadow"]
 
 
+@pytest.mark.parametrize("key", sorted(FC))
+def test_full_size_frames_against_the_reference(P, oracle, key):
+    """BASELINE's configs at full size against the REAL reference: 20000 seeded pixels whose
+    camera rays (centre + MSAA offsets) went through the reference's own performRayTracing
+    (tools/make_sparse_ref.py, fixture sparse_ref_*.npz).  That build has no image library, so
+    both sides render the scene untextured."""
+    cfg = FC[key]
+    g = np.load(os.path.join(GOLDEN, f"sparse_ref_{key}.npz"))
+    hs = P.host.HostScene(os.path.join(SCENES, cfg["scene"] + ".obj"), textures=False)
+    gs = hs.to_gpu(0)
+    W, H = cfg["width"], cfg["height"]
+    rgb, depth, tri, st = gs.render(g["corners"], g["lights"], P.capi.default_params(W, H, cfg["msaa"]))
+    x, y = g["x"], g["y"]
+    assert (tri[y, x] == g["tri"]).mean() >= 0.9999          # triangle of the pixel-centre ray
+    d = np.abs(oracle.to_bytes(rgb[y, x]).astype(int) - g["rgb8"].astype(int)).max(axis=1)
+    assert (d <= 1).mean() >= 0.999, f"{(d > 1).sum()} of {d.size} sampled pixels off by > 1 LSB"
+    assert (d == 0).mean() >= 0.98
+    miss = g["depth"] == FLT_MAX
+    assert ((depth[y, x] == FLT_MAX) == miss).mean() >= 0.9999
+    both = ~miss & (depth[y, x] != FLT_MAX)
+    if cfg["msaa"] == 1:     # the camera ray's own t: bit-exact
+        assert (depth[y, x][both] == g["depth"][both]).mean() >= 0.9999
+    else:                    # mean of the samples' t, same order of additions
+        assert (np.abs(depth[y, x][both] - g["depth"][both]) <= 1e-6 * g["depth"][both]).mean() >= 0.9995
+
+
 def test_bad_arguments_are_rejected(P):
     hs, gs, m, lights = _host_gpu(P, "ball")
     L = P.capi.lib()

@@ -108,3 +108,34 @@ def test_gpu_r_path_files_equal_reference(g, tmp_path):
     a, b = file_bytes(tmp_path, "blurred.bmp").astype(int), g["blurred_bmp"].astype(int)
     assert a.size == b.size and np.array_equal(a[:54], b[:54])
     assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.999
+
+
+@pytest.mark.gpu
+def test_gpu_fused_postprocess_equals_reference_and_the_separate_calls(g):
+    """rt_postprocess_device: first normalisation in place, second one folded into the blur."""
+    import ctypes as C
+
+    import torch
+    P = pkg()
+    L = P.capi.lib()
+    focus = float(g["focus"])
+    H, W = g["depth_in"].shape
+    rgb = torch.from_numpy(g["image"]).cuda()
+    depth = torch.from_numpy(g["depth_in"]).cuda()
+    out = torch.zeros((H - 12, W - 12, 3), dtype=torch.float32, device="cuda")
+    P.capi.check(L.rt_postprocess_device(0, W, H, focus, 2.5, C.c_void_p(rgb.data_ptr()), C.c_void_p(depth.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(depth.cpu().numpy(), g["depth1"])
+    got, ref = out.cpu().numpy(), g["blurr"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.abs(got[ok] - ref[ok]).max() < 2e-6
+    d2 = P.capi.normalize_depth(P.capi.normalize_depth(g["depth_in"], focus), focus)
+    sep = P.capi.dof_blur(g["image"], d2)
+    assert np.array_equal(got[ok], sep[ok])
+    # without a blur buffer only the depth plane is produced
+    depth = torch.from_numpy(g["depth_in"]).cuda()
+    P.capi.check(L.rt_postprocess_device(0, W, H, focus, 2.5, None, C.c_void_p(depth.data_ptr()), None, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(depth.cpu().numpy(), g["depth1"])

@@ -71,3 +71,19 @@ def test_golden_rays_come_from_the_committed_camera(case, oracle):
     assert np.array_equal(oracle.camera_corners(m, W, H), g["corners"])
     o, d = oracle.pixel_ray(g["corners"], W, H, 0, 0)
     assert np.array_equal(o, g["origins"][0]) and np.array_equal(d, g["dests"][0])
+
+
+@pytest.mark.parametrize("name,W,H", [("ball", 800, 800), ("redballs", 1920, 1080), ("refractionballs", 1920, 1080)])
+def test_full_size_pixels_equal_reference(oracle, name, W, H):
+    """Full-resolution camera rays of the MSAA-1 configs: the oracle's pixel ray + shading
+    recursion against the reference's answers for the same 20000 pixels (untextured build)."""
+    g = load_golden(f"sparse_ref_{name}_{W}x{H}_msaa1")
+    s = oracle.Scene.load(os.path.join(SCENES, name + ".obj"), textures=False)
+    s.set_lights(g["lights"])
+    o = np.zeros((len(g["x"]), 3), np.float32)
+    d = np.zeros_like(o)
+    for i, (x, y) in enumerate(zip(g["x"], g["y"])):
+        o[i], d[i] = oracle.pixel_ray(g["corners"], W, H, float(x), float(y))
+    rgb, min_t, tri = s.trace_rays(o, d, threads=8)
+    assert np.array_equal(tri, g["tri"]) and np.array_equal(min_t, g["depth"])
+    assert np.array_equal(np.clip(rgb, 0, 1), g["rgb"])
