@@ -17,9 +17,18 @@ GPUs executed).  roofline.achieved = algorithmic FLOP of the dominant kernel
 divided by its duration from HIP events recorded inside the timed loop; the FLOP
 count is F = 45 T + 40 S + 30 H + 60 Hl + 25 C with the counters of the
 reference's algorithm (tests/golden/frame_counters.json, produced by
-tools/make_counters.py and tools/make_centre_primary.py on the CPU oracle), less
-the work whose result the reference never uses (shading of the pixel-centre
-rays, shadow queries that cannot change shadowMax).
+tools/make_counters.py on the CPU oracle), less the work whose result the
+reference never uses (shading of the pixel-centre rays, shadow queries that
+cannot change shadowMax).  That figure measures the frame against a machine
+running the REFERENCE's walk at peak rate; roofline.executed prices, with the
+same weights, the tests, node steps, shaded hits and child rays the launch
+really executed (its own counters) - that one is the hardware utilisation.
+
+After the timed loop, outside it, the last frame is checked: sparse pixels
+against the committed fixture of the CPU oracle, blurred pixels against the
+oracle's kernel; a mismatch fails the run ("checked" in the line).  On one GPU
+the line also carries a record per other BASELINE config ("configs"), the wall
+time of the drop-in 'r' path ("r_path_ms") and the CPU baseline.
 """
 import argparse
 import importlib
@@ -39,18 +48,30 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak (= f32 MFMA peak)
 HBM_PEAK_GBS = 8000.0
 
 
+def cpu_share():
+    """Host threads this process may use: the affinity mask, capped by the pool's per-GPU share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+
+
 def cpu_baseline(corners, lights):
-    """The oracle (CPU restatement of the reference) on a bounded sample of the
-    same frame: 6 bands of rows spread over the image, all host threads we may
-    use.  Checker code used as a reported baseline, never as the product."""
+    """The oracle (CPU restatement of the reference) on a bounded sample of the same frame,
+    by the reference's own protocol (key 'R', main.cpp:261-267: mean of 5 runs) after one
+    warm-up run, at the two thread counts the survey names: the reference's policy
+    min(16, hardware threads - 1) (config.h.dist:23, main.cpp:331) and every thread we may
+    use.  The sample is 6 bands of rows spread over the image; the per-frame figure is
+    extrapolated from it.  Checker code used as a reported baseline, never as the product."""
     from oracle import oracle as O
-    threads = max(1, min(16, os.cpu_count() or 1))
+    share = cpu_share()
     s = O.Scene.load(os.path.join(ROOT, "scenes", SCENE + ".obj"))
     s.set_lights(lights)
     s.settings.MSAA = MSAA
     bands = 6
 
-    def sample(rows):
+    def sample(rows, threads):
         c = O.Counters()
         out = None
         t0 = time.perf_counter()
@@ -59,16 +80,134 @@ def cpu_baseline(corners, lights):
             out = s.render(corners, W, H, y0=y0, y1=y0 + rows, threads=threads, counters=c, out=out)
         return c, time.perf_counter() - t0
 
+    policies = [("reference_policy", max(1, min(16, share - 1))), ("all_threads", share)]
+    res = {}
     rows = 2
-    c, dt = sample(rows)                       # calibration pass
-    target = 15.0                              # seconds of CPU wall time for the timed sample
-    rows = int(max(2, min(H // bands, rows * target / max(dt, 1e-3))))
-    c, dt = sample(rows)
-    rays = c.rays_closest + c.rays_shadow
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{bands * rows} of {H} rows ({bands} bands) of {SCENE}.obj {W}x{H} MSAA{MSAA}, "
-                      f"no DoF, {dt:.1f} s",
-            "ms_per_frame_extrapolated": round(dt * H / (bands * rows) * 1e3, 1)}
+    for name, threads in policies:
+        c, dt = sample(2, threads)                   # warm-up, also sizes the sample: ~1.6 s per run
+        rows = int(max(2, min(H // bands, 2 * 1.6 / max(dt, 1e-3))))
+        times = []
+        for _ in range(5):
+            c, dt = sample(rows, threads)
+            times.append(dt)
+        dt = sum(times) / len(times)
+        rays = c.rays_closest + c.rays_shadow
+        res[name] = {"threads": threads, "mrays_s": round(rays / dt / 1e6, 3),
+                     "ms_per_frame_extrapolated": round(dt * H / (bands * rows) * 1e3, 1),
+                     "rows": bands * rows, "runs": 5, "mean_run_s": round(dt, 3)}
+    best = max(res.values(), key=lambda r: r["mrays_s"])
+    return {"value": best["mrays_s"], "unit": "Mrays/s", "cores": best["threads"], "kind": "port",
+            "host_cpu_count": os.cpu_count(), "cpu_share": share, "extrapolated": True,
+            "protocol": "mean of 5 runs after 1 warm-up (main.cpp:261-267), render loop only, no file writes",
+            "sample": f"{best['rows']} of {H} rows ({bands} bands) of {SCENE}.obj {W}x{H} MSAA{MSAA}, no DoF, "
+                      f"5 x {best['mean_run_s']:.1f} s",
+            "ms_per_frame_extrapolated": best["ms_per_frame_extrapolated"], "policies": res}
+
+
+OTHER_CONFIGS = [("ball", 800, 800, 1), ("redballs", 1920, 1080, 1), ("refractionballs", 1920, 1080, 1),
+                 ("lego", 3840, 2160, 4)]
+
+
+def r_path_ms(pkg, dev_index):
+    """Wall time of the drop-in 'r' path for the headline config through the C++ host
+    (RayTracer::doDaRayTracingShizz: frame + post-process on the GPU, planes to the host, four
+    files written), second of two runs; the scene is loaded and resident before the clock starts."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        t = pkg.host.time_r_path(os.path.join(ROOT, "scenes", SCENE + ".obj"),
+                                 os.path.join(ROOT, "scenes", "cameras", SCENE + ".sav"), W, H, MSAA, tmp,
+                                 dev_index, runs=2)
+    return t
+
+
+def executed_flop(st, n_lights):
+    """The survey's weights on the work a launch really executed (its own counters)."""
+    return (45 * st.tri_tests + 40 * st.node_visits + 30 * st.shaded_hits
+            + 60 * st.shaded_hits * n_lights + 25 * st.child_rays)
+
+
+def config_record(pkg, name, w, h, msaa, fc, dev_index, frames=5):
+    """One of the other BASELINE configs, render only: ms per frame from HIP events around the
+    launch, rays from one counted frame, sparse pixels checked against the oracle's fixture."""
+    import torch
+    capi, host = pkg.capi, pkg.host
+    hs = host.HostScene(os.path.join(ROOT, "scenes", name + ".obj"))
+    gs = hs.to_gpu(dev_index)
+    m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", name + ".sav"))
+    corners = host.camera_corners(m, w, h)
+    p = capi.default_params(w, h, msaa)
+    dev = torch.device("cuda", dev_index)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    depth = torch.zeros((h, w), dtype=torch.float32, device=dev)
+    tri = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    st = gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), tri.data_ptr(), 0, True)
+    gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0, False)
+    torch.cuda.synchronize()
+    gs.set_timing(True)
+    for _ in range(frames):
+        gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0, False)
+    torch.cuda.synchronize()
+    kt = gs.collect_timing()
+    gs.set_timing(False)
+    ms = kt.frame_ms / max(kt.frames, 1)
+    rays = st.rays_closest + st.rays_shadow
+    key = f"{name}_{w}x{h}_msaa{msaa}"
+    rec = {"ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1), "rays_per_frame": int(rays),
+           "lights": len(lights), "launches_timed": kt.frames}
+    if fc.get(key):
+        f_needed = fc[key].get("flops_needed", fc[key]["flops_frame"])
+        rec["frac"] = round(f_needed / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+        rec["frac_executed"] = round(executed_flop(st, len(lights)) / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+    rec["checked"] = check_sparse(key, rgb.cpu().numpy(), depth.cpu().numpy(), tri.cpu().numpy())
+    gs.close()
+    return rec
+
+
+def check_sparse(key, rgb, depth, tri=None):
+    """20000 seeded pixels of the full-size frame against the committed fixture of the CPU
+    oracle (tests/golden/sparse_<config>.npz): 8-bit RGB within 1 LSB on >= 99.9 %, misses agree
+    and depth within 1e-5 on >= 99.95 %, pixel-centre triangle equal on >= 99.99 %."""
+    from oracle import oracle as O
+    path = os.path.join(ROOT, "tests", "golden", f"sparse_{key}.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    x, y = g["x"], g["y"]
+    d = np.abs(O.to_bytes(rgb[y, x]).astype(int) - g["rgb8"].astype(int)).max(axis=1)
+    ok = (d <= 1).mean() >= 0.999
+    miss = g["depth"] == np.float32(3.402823466e+38)
+    got = depth[y, x]
+    ok = ok and ((got == np.float32(3.402823466e+38)) == miss).mean() >= 0.9999
+    both = ~miss & (got != np.float32(3.402823466e+38))
+    ok = ok and (np.abs(got[both] - g["depth"][both]) <= 1e-5 * g["depth"][both]).mean() >= 0.9995
+    if tri is not None:
+        ok = ok and (tri[y, x] == g["tri"]).mean() >= 0.9999
+    return bool(ok)
+
+
+def check_blur(rgb, depth1, blurred, focus, depth_power, n=300):
+    """n seeded pixels of the blurred frame against the oracle's kernel (gauseanMap of the twice
+    normalised depth, 169 taps in the reference's order) on the frame's own colour plane."""
+    from oracle import oracle as O
+    hh, ww = depth1.shape
+    d2 = O.normalize_depth(depth1, focus)
+    rng = np.random.Generator(np.random.PCG64(1806))
+    xs, ys = rng.integers(6, ww - 6, n), rng.integers(6, hh - 6, n)
+    worst = 0.0
+    for x, y in zip(xs, ys):
+        m = O.gaussian_map(float(d2[y, x]), depth_power)
+        acc = np.zeros(3, np.float32)
+        win = rgb[y - 6:y + 7, x - 6:x + 7]
+        for j in range(13):
+            for k in range(13):
+                acc = (acc + win[j, k] * m[j, k]).astype(np.float32)
+        got = blurred[y - 6, x - 6]
+        if np.isnan(acc).any() or np.isnan(got).any():
+            if not (np.isnan(acc).all() and np.isnan(got).all()):
+                return False
+            continue
+        worst = max(worst, float(np.abs(acc - got).max()))
+    return worst < 2e-6
 
 
 def main():
@@ -77,6 +216,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the per-config records and the 'r' path timing (profiling runs)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently per GPU (each with its own workspace and stream); "
                          "default 1 on one GPU, 2 on several")
@@ -239,6 +380,7 @@ def main():
     my_rays = st.rays_closest + st.rays_shadow
     my = torch.tensor([float(my_rays), float(st.tri_tests), float(st.node_visits)],
                       dtype=torch.float64, device=dev)
+    my_executed_flop = executed_flop(st, len(lights))      # this rank's launch
     if world > 1:
         if backend == "gloo":
             my_c = my.cpu()
@@ -283,6 +425,26 @@ def main():
               file=sys.stderr, flush=True)
         if not same:
             raise SystemExit(2)
+    checked = None
+    if rank == 0:
+        # outside the timed region: the frame the loop produced last, against the oracle's fixtures
+        torch.cuda.synchronize()
+        last = slots[(args.steps - 1) % n_flight] if args.steps > 0 else slots[0]
+        h_rgb, h_depth1 = last["rgb"].cpu().numpy(), last["depth"].cpu().numpy()
+        raw = torch.zeros_like(last["depth"])               # the depth plane before normalisation
+        p1 = capi.default_params(W, H, MSAA)
+        tmp_rgb = torch.zeros_like(last["rgb"])
+        gs.render_device(corners, lights, p1, tmp_rgb.data_ptr(), raw.data_ptr(), 0, 0, False)
+        torch.cuda.synchronize()
+        same_rgb = bool((tmp_rgb == last["rgb"]).all().item())
+        ok_sparse = check_sparse(f"{SCENE}_{W}x{H}_msaa{MSAA}", h_rgb, raw.cpu().numpy())
+        from oracle import oracle as O
+        ok_depth = bool(np.array_equal(O.normalize_depth(raw.cpu().numpy(), p.focusDepth), h_depth1))
+        ok_blur = check_blur(h_rgb, h_depth1, last["blurred"].cpu().numpy(), p.focusDepth, p.depthPower)
+        checked = bool(same_rgb and ok_sparse and ok_depth and ok_blur)
+        if not checked:
+            print(f"bench check FAILED: frame equals a fresh render {same_rgb}, sparse pixels {ok_sparse}, "
+                  f"depth normalisation {ok_depth}, blur {ok_blur}", file=sys.stderr, flush=True)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = rays_per_frame * args.steps / elapsed / 1e6
@@ -290,7 +452,7 @@ def main():
             "metric": "Mrays/s (all bounces), final.obj 3840x2160 MSAA4 + DoF; ms/frame in ms_per_step",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "checked": checked,
             "data": "scenes/final.obj + scenes/cameras/final.sav (the reference's own scene; no "
                     "published camera exists, this one is fixed in the repo)",
             "config": {"workload": f"{SCENE}.obj {W}x{H} MSAA{MSAA} + DoF, {len(lights)} lights, "
@@ -331,7 +493,8 @@ def main():
                 if os.path.exists(tp):
                     traffic = json.load(open(tp)).get("k_wf_pipeline_hbm_bytes_per_launch")
                 hbm_bytes = W * H * 16 + W * H * 16 + (W - 12) * (H - 12) * 12
-                roof = {"bound": "mfma", "bound_detail": "fp32 vector ALU; the path has no matrix-shaped work, "
+                exe = my_executed_flop
+                roof = {"bound": "mfma", "bound_is_vector_fp32": True, "bound_detail": "fp32 vector ALU; the path has no matrix-shaped work, "
                         "so the ceiling is the FP32 rate, which is the same 157.3 TFLOP/s for vector FMA "
                         "and dense f32 MFMA", "kernel": "k_wf_pipeline", "achieved": round(ach, 3),
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
@@ -341,6 +504,13 @@ def main():
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "frac_reference_walk": round(
                             fc["flops_frame"] * frac0 / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        "executed": {"gflop_per_launch": round(exe / 1e9, 2),
+                                     "achieved": round(exe / (kern_ms * 1e-3) / 1e12, 3),
+                                     "frac": round(exe / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                     "what": "45 x tests + 40 x node steps + 30 x shaded hits + 60 x hit-light "
+                                             "pairs + 25 x child rays as this launch executed them (its own "
+                                             "counters): the hardware utilisation; frac above is the frame "
+                                             "measured against the reference's walk"},
                         "note": "no MFMA on this path: the bound is the FP32 vector peak (= the f32 MFMA "
                                 "peak, 157.3 TFLOP/s); algorithmic flop follow the reference's own walk "
                                 "(T = %d ray/triangle tests, S = %d leaf steps per frame)"
@@ -363,9 +533,16 @@ def main():
         if n_flight == 1:
             out["kernel_ms"]["dof_and_gather"] = round(ms - kt.frame_ms / max(kt.frames, 1), 3)
         out["config"]["frames_in_flight"] = n_flight
+        if world == 1 and not args.no_extras:
+            fc_all = json.load(open(fc_path)) if os.path.exists(fc_path) else {}
+            out["configs"] = {f"{n_}_{w_}x{h_}_msaa{m_}": config_record(pkg, n_, w_, h_, m_, fc_all, local)
+                              for n_, w_, h_, m_ in OTHER_CONFIGS}
+            out["r_path_ms"] = r_path_ms(pkg, local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)
         print(json.dumps(out), flush=True)
+        if checked is False or any(c.get("checked") is False for c in out.get("configs", {}).values()):
+            raise SystemExit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -118,6 +118,8 @@ typedef struct RtStats {
     uint64_t camera_rays;  /* camera samples evaluated (incl. centre visibility rays) */
     float    kernel_ms;    /* HIP-event time of the call's kernels */
     float    reserved;
+    uint64_t shaded_hits;  /* closest hits that were shaded (raytracing.cpp:76-164) */
+    uint64_t child_rays;   /* reflection / refraction rays spawned (raytracing.cpp:166-271) */
 } RtStats;
 
 /* The scene as laid out on the device: the reference's tree with its inner-node
@@ -186,6 +188,19 @@ int rt_trace_rays(RtScene *scene, const float *lights, int32_t n_lights, const R
 int rt_render_frame(RtScene *scene, const float camera[24], const float *lights, int32_t n_lights,
                     const RtParams *params, float *rgb, float *depth, int32_t *tri,
                     RtStats *stats);
+
+/* The whole 'r' path (main.cpp:322-378 without the file writes) with the frame kept on the
+ * device: the frame, Image::normailzeDepthRange twice and the blur, then the three 8-bit
+ * planes the reference's writers derive from them - rgb8: (unsigned char)(v*255.0f) of the
+ * colour plane, width*height*3, RGB order (imageWriter.h:270, 322-324); depth8: the grey value
+ * of depth.bmp, (unsigned char)((1-depth)*255.0f) of the plane normalised once, width*height
+ * (imageWriter.h:387); blurred8: the blurred plane quantised the same way, (width-12)*
+ * (height-12)*3, NULL for frames too small to blur (imageWriter.h:452-454).  The pointers
+ * returned lie in pinned host memory owned by the scene; they stay valid until the next call
+ * on this scene or rt_scene_destroy.  Whole frames only (params->tile_w == 0). */
+int rt_render_result_planes(RtScene *scene, const float camera[24], const float *lights,
+                            int32_t n_lights, const RtParams *params, const uint8_t **rgb8,
+                            const uint8_t **depth8, const uint8_t **blurred8, RtStats *stats);
 
 /* Same with device pointers on the scene's device, enqueued on `stream`
  * (a hipStream_t).  Pixels outside this rank's tiles are not written.  With

@@ -59,7 +59,7 @@ class RtParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("node_visits", C.c_uint64), ("camera_rays", C.c_uint64), ("kernel_ms", C.c_float),
-                ("reserved", C.c_float)]
+                ("reserved", C.c_float), ("shaded_hits", C.c_uint64), ("child_rays", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -78,7 +78,7 @@ class RtSceneInfo(C.Structure):
 
 EXPORTS = [
     "rt_default_params", "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
-    "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device",
+    "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device", "rt_render_result_planes",
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
     "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
 ]
@@ -121,6 +121,8 @@ def lib():
     L.rt_render_frame.argtypes = [P, P, P, I32, C.POINTER(RtParams), P, P, P, C.POINTER(RtStats)]
     L.rt_render_frame_device.argtypes = [P, P, P, I32, C.POINTER(RtParams), P, P, P, P,
                                          C.POINTER(RtStats)]
+    L.rt_render_result_planes.argtypes = [P, P, P, I32, C.POINTER(RtParams), C.POINTER(P), C.POINTER(P),
+                                          C.POINTER(P), C.POINTER(RtStats)]
     L.rt_normalize_depth.argtypes = [C.c_int, I64, F, P]
     L.rt_normalize_depth_device.argtypes = [C.c_int, I64, F, P, P]
     L.rt_normalize_depth_device_noalloc.argtypes = [C.c_int, I64, F, P, P]

@@ -9,9 +9,12 @@
 //     rows are laid out with the 4-byte-aligned stride but only 3*w*h bytes are
 //     written (imageWriter.h:316-331), so widths that are not a multiple of 4
 //     come out skewed exactly as the reference's do;
-//   * depth.bmp: grey = 1 - normalised depth, and the reference's inner loop
-//     runs over 3*w "pixels" per row (imageWriter.h:379-389), overwriting the
-//     following rows' start; reproduced by writing in the same order;
+//   * depth.bmp: grey = 1 - normalised depth.  The reference's inner loop runs
+//     over 3*w "pixels" per row (imageWriter.h:379-389) and so scribbles over
+//     the two rows that follow, but every row rewrites its own bytes and its
+//     padding afterwards and the index guard keeps the last rows inside the
+//     buffer: what is left in the end is plain grey rows plus padding bytes of
+//     value 1, which is what is written here directly;
 //   * the three BMP writers fill one byte buffer that belongs to the Image
 //     (imageWriter.h:239) and blurred.bmp's padding loop writes three bytes
 //     early (imageWriter.h:456-458), so for widths whose rows need padding the
@@ -52,7 +55,19 @@ void putHeaders(FILE* f, unsigned sizeField, int w, int h)
 
 inline int stride(int w) { return ((24 * w + 31) / 32) * 4; }
 
-bool writeColour(const char* filename, const float* img, int w, int h, unsigned sizeField, int padShift,
+// The 8-bit form of a float plane: the given bytes if the GPU already made them, else quantised here.
+const unsigned char* bytesOf(const unsigned char* ready, const std::vector<float>& plane,
+                             std::vector<unsigned char>& tmp)
+{
+    if (ready) return ready;
+    tmp.resize(plane.size());
+    for (size_t i = 0; i < plane.size(); ++i) tmp[i] = quantize(plane[i]);
+    return tmp.data();
+}
+
+// rgb: w*h*3 bytes in RGB order.  padShift: how many bytes early the padding loop writes
+// (imageWriter.h:326-328 writes in place, :456-458 three bytes early).
+bool writeColour(const char* filename, const unsigned char* rgb, int w, int h, unsigned sizeField, int padShift,
                  std::vector<unsigned char>& bytes)
 {
     FILE* f = fopen(filename, "wb");
@@ -64,14 +79,14 @@ bool writeColour(const char* filename, const float* img, int w, int h, unsigned 
     const int rs = stride(w);
     if (bytes.size() < (size_t)rs * h + 8) bytes.resize((size_t)rs * h + 8, 0);
     for (int y = 0; y < h; ++y) {
-        unsigned char* row = bytes.data() + (size_t)y * rs;
-        const float*   src = img + (size_t)y * w * 3;
+        unsigned char*       row = bytes.data() + (size_t)y * rs;
+        const unsigned char* src = rgb + (size_t)y * w * 3;
         for (int x = 0; x < w; ++x) {
-            row[3 * x] = quantize(src[3 * x + 2]);
-            row[3 * x + 1] = quantize(src[3 * x + 1]);
-            row[3 * x + 2] = quantize(src[3 * x]);
+            row[3 * x] = src[3 * x + 2];
+            row[3 * x + 1] = src[3 * x + 1];
+            row[3 * x + 2] = src[3 * x];
         }
-        for (int i = 3 * w; i < rs; ++i) row[i - padShift] = 1; // imageWriter.h:326-328 / 456-458
+        for (int i = 3 * w; i < rs; ++i) row[i - padShift] = 1;
     }
     const bool ok = fwrite(bytes.data(), (size_t)w * h * 3, 1, f) == 1;
     if (!ok) fprintf(stderr, "Dump file problem... fwrite\n");
@@ -89,16 +104,16 @@ bool Image::writeImagePPM(const char* filename) const
         return false;
     }
     fprintf(f, "P6\n%i %i\n255\n", width, height);
-    std::vector<unsigned char> bytes(rgb.size());
-    for (size_t i = 0; i < rgb.size(); ++i) bytes[i] = quantize(rgb[i]);
-    const bool ok = fwrite(bytes.data(), (size_t)width * height * 3, 1, f) == 1;
+    std::vector<unsigned char> tmp;
+    const bool ok = fwrite(bytesOf(rgb8, rgb, tmp), (size_t)width * height * 3, 1, f) == 1;
     fclose(f);
     return ok;
 }
 
 bool Image::writeImageBMP(const char* filename) const
 {
-    return writeColour(filename, rgb.data(), width, height, (unsigned)(3 * width * height), 0, imageC);
+    std::vector<unsigned char> tmp;
+    return writeColour(filename, bytesOf(rgb8, rgb, tmp), width, height, (unsigned)(3 * width * height), 0, imageC);
 }
 
 // imageWriter.h:472-488: rows y..y+h-1, columns x..x+w-1 into the file writeImageBMP made
@@ -109,10 +124,10 @@ bool Image::writeImageBMP(const char* filename, int x, int y, int w, int h) cons
     std::vector<unsigned char> row((size_t)w * 3);
     for (int Y = y; Y < y + h; ++Y) {
         for (int j = x; j < x + w; ++j) {
-            const float* src = rgb.data() + ((size_t)Y * width + j) * 3;
-            row[(size_t)(j - x) * 3] = quantize(src[2]);
-            row[(size_t)(j - x) * 3 + 1] = quantize(src[1]);
-            row[(size_t)(j - x) * 3 + 2] = quantize(src[0]);
+            const size_t   p = ((size_t)Y * width + j) * 3;
+            unsigned char* d = &row[(size_t)(j - x) * 3];
+            if (rgb8) d[0] = rgb8[p + 2], d[1] = rgb8[p + 1], d[2] = rgb8[p];
+            else d[0] = quantize(rgb[p + 2]), d[1] = quantize(rgb[p + 1]), d[2] = quantize(rgb[p]);
         }
         fseek(f, 54 + ((long)Y * w + x) * 3, SEEK_SET);
         fwrite(row.data(), 1, row.size(), f);
@@ -124,9 +139,10 @@ bool Image::writeImageBMP(const char* filename, int x, int y, int w, int h) cons
 bool Image::writeBlurredBMP(const char* filename) const
 {
     const int bw = width - 12, bh = height - 12;
-    if (bw <= 0 || bh <= 0 || blurred.size() != (size_t)bw * bh * 3) return false;
+    if (bw <= 0 || bh <= 0 || (!blurred8 && blurred.size() != (size_t)bw * bh * 3)) return false;
     if (imageC.size() < (size_t)stride(width) * height + 8) imageC.resize((size_t)stride(width) * height + 8, 0);
-    return writeColour(filename, blurred.data(), bw, bh, (unsigned)(bw * bh), 3, imageC);
+    std::vector<unsigned char> tmp;
+    return writeColour(filename, bytesOf(blurred8, blurred, tmp), bw, bh, (unsigned)(bw * bh), 3, imageC);
 }
 
 bool Image::writeDepthBMP(const char* filename) const
@@ -137,21 +153,18 @@ bool Image::writeDepthBMP(const char* filename) const
         return false;
     }
     putHeaders(f, (unsigned)(3 * width * height), width, height);
-    const int                  rs = stride(width);
-    const size_t               npx = (size_t)width * height;
+    const int                   rs = stride(width);
+    const size_t                npx = (size_t)width * height;
     std::vector<unsigned char>& bytes = imageC;
     if (bytes.size() < (size_t)rs * height + 8) bytes.resize((size_t)rs * height + 8, 0);
     for (int y = 0; y < height; ++y) {
-        int i = 0;
-        for (; i < width * 3; ++i) {
-            const size_t p = (size_t)y * width + i;
-            if (p < npx) {
-                const unsigned char v = quantize(1 - depth[p]);
-                unsigned char*      d = bytes.data() + (size_t)y * rs + (size_t)i * 3;
-                d[0] = d[1] = d[2] = v;
-            }
+        unsigned char* row = bytes.data() + (size_t)y * rs;
+        for (int x = 0; x < width; ++x) {
+            const size_t        p = (size_t)y * width + x;
+            const unsigned char v = depth8 ? depth8[p] : quantize(1 - depth[p]);
+            row[3 * x] = row[3 * x + 1] = row[3 * x + 2] = v;
         }
-        for (; i < rs; ++i) bytes[(size_t)y * rs + i] = 1;
+        for (int i = 3 * width; i < rs; ++i) row[i] = 1;
     }
     const bool ok = fwrite(bytes.data(), npx * 3, 1, f) == 1;
     fclose(f);

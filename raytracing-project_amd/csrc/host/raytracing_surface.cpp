@@ -152,7 +152,7 @@ bool RayTracer::setFocusAtPixel(double x, double y)
     return true;
 }
 
-double RayTracer::doDaRayTracingShizz(const char* out_dir)
+double RayTracer::doDaRayTracingShizz(const char* out_dir, bool floatPlanes, bool rowUpdates)
 {
     if (!g_scene) {
         g_error = "doDaRayTracingShizz: init() has not succeeded";
@@ -160,43 +160,62 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir)
     }
     const int W = result.width, H = result.height;
     fprintf(stderr, "\nRaytracing a complete %i x %i image \n", W, H);
+    const std::string dir = std::string(out_dir && *out_dir ? out_dir : ".") + "/";
+    if (rowUpdates) Image(W, H).writeImageBMP((dir + "result.bmp").c_str()); // main.cpp:325
     RtParams p = MySettings;
     p.width = W, p.height = H;
     p.focusDepth = focusDepth;
     p.tile_w = p.tile_h = 0, p.rank = 0, p.world = 1;
     std::vector<float> l = lightArray();
     const auto         t0 = std::chrono::steady_clock::now();
-    if (rt_render_frame(g_scene, corners, l.data(), (int32_t)MyLightPositions.size(), &p,
-                        result.rgb.data(), result.depth.data(), nullptr, &stats) != RT_OK) {
-        fail("rt_render_frame");
-        return -1.0;
+    result.rgb8 = result.depth8 = result.blurred8 = nullptr;
+    if (!floatPlanes) {
+        if (rt_render_result_planes(g_scene, corners, l.data(), (int32_t)MyLightPositions.size(), &p, &result.rgb8,
+                                    &result.depth8, &result.blurred8, &stats) != RT_OK) {
+            fail("rt_render_result_planes");
+            return -1.0;
+        }
+    } else {
+        if (rt_render_frame(g_scene, corners, l.data(), (int32_t)MyLightPositions.size(), &p, result.rgb.data(),
+                            result.depth.data(), nullptr, &stats) != RT_OK) {
+            fail("rt_render_frame");
+            return -1.0;
+        }
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "\nRaytracing comlete in %g seconds, storing result...\n", secs);
-    const std::string dir = std::string(out_dir && *out_dir ? out_dir : ".") + "/";
-    bool              ok = result.writeImagePPM((dir + "result.ppm").c_str());
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rowUpdates) // main.cpp:407, one update per finished row
+        for (int y = 0; y < H; ++y) result.writeImageBMP((dir + "result.bmp").c_str(), 0, y, W, 1);
+    bool ok = result.writeImagePPM((dir + "result.ppm").c_str());
     ok = result.writeImageBMP((dir + "result.bmp").c_str()) && ok;
-    // writeDepthBMP normalises the depth plane, writeBlurredBMP normalises it a
-    // second time before blurring (imageWriter.h:352, 416)
-    const int64_t npx = (int64_t)W * H;
-    if (rt_normalize_depth(g_device, npx, focusDepth, result.depth.data()) != RT_OK) {
-        fail("rt_normalize_depth");
-        return -1.0;
-    }
-    ok = result.writeDepthBMP((dir + "depth.bmp").c_str()) && ok;
-    if (W > 12 && H > 12) {
+    if (floatPlanes) {
+        // writeDepthBMP normalises the depth plane, writeBlurredBMP normalises it a
+        // second time before blurring (imageWriter.h:352, 416)
+        const int64_t npx = (int64_t)W * H;
         if (rt_normalize_depth(g_device, npx, focusDepth, result.depth.data()) != RT_OK) {
             fail("rt_normalize_depth");
             return -1.0;
         }
-        result.blurred.assign((size_t)(W - 12) * (H - 12) * 3, 0.0f);
-        if (rt_dof_blur(g_device, W, H, p.depthPower, result.rgb.data(), result.depth.data(),
-                        result.blurred.data()) != RT_OK) {
-            fail("rt_dof_blur");
-            return -1.0;
+    }
+    ok = result.writeDepthBMP((dir + "depth.bmp").c_str()) && ok;
+    if (W > 12 && H > 12) {
+        if (floatPlanes) {
+            std::vector<float> twice = result.depth;
+            if (rt_normalize_depth(g_device, (int64_t)W * H, focusDepth, twice.data()) != RT_OK) {
+                fail("rt_normalize_depth");
+                return -1.0;
+            }
+            result.blurred.assign((size_t)(W - 12) * (H - 12) * 3, 0.0f);
+            if (rt_dof_blur(g_device, W, H, p.depthPower, result.rgb.data(), twice.data(), result.blurred.data()) !=
+                RT_OK) {
+                fail("rt_dof_blur");
+                return -1.0;
+            }
         }
         ok = result.writeBlurredBMP((dir + "blurred.bmp").c_str()) && ok;
     }
+    files_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     if (!ok) {
         g_error = "could not write the result files into " + dir;
         return -1.0;
@@ -309,6 +328,38 @@ double rth_render_to_files(const char* obj_path, const char* camera_sav, int w, 
     if (stats) *stats = r.stats;
     shutdown();
     return secs;
+}
+// the same through the float planes (result.rgb / depth / blurred filled), optionally with the
+// per-row updates of result.bmp
+double rth_render_to_files_float(const char* obj_path, const char* camera_sav, int w, int h, int msaa,
+                                 const char* out_dir, int device, int row_updates)
+{
+    if (!init(obj_path, device, true)) return -1.0;
+    double modelview[16];
+    if (!readCameraSav(camera_sav, modelview, MyLightPositions)) return -2.0;
+    MySettings.msaa = msaa;
+    RayTracer    r(modelview, w, h);
+    const double secs = r.doDaRayTracingShizz(out_dir, true, row_updates != 0);
+    shutdown();
+    return secs;
+}
+// `runs` times the 'r' path on a resident scene; out[0] = seconds of the last run's frame call
+// (GPU frame + post-process + planes to the host), out[1] = seconds it spent writing the files
+int rth_time_r_path(const char* obj_path, const char* camera_sav, int w, int h, int msaa, const char* out_dir,
+                    int device, int runs, double out[2])
+{
+    if (!init(obj_path, device, true)) return -1;
+    double modelview[16];
+    if (!readCameraSav(camera_sav, modelview, MyLightPositions)) return -2;
+    MySettings.msaa = msaa;
+    RayTracer r(modelview, w, h);
+    for (int i = 0; i < runs; ++i) {
+        out[0] = r.doDaRayTracingShizz(out_dir);
+        out[1] = r.files_seconds;
+        if (out[0] < 0) return -3;
+    }
+    shutdown();
+    return 0;
 }
 // the same after key 'f' at pixel (fx, fy); *focus receives the focus depth used
 double rth_render_to_files_focus(const char* obj_path, const char* camera_sav, int w, int h, int msaa,

@@ -72,6 +72,10 @@ void cameraCorners(const double modelview[16], int width, int height, float corn
 struct Image {
     int                width = 0, height = 0;
     std::vector<float> rgb, depth, blurred;
+    // The same three planes as the writers quantise them, when the GPU has already done that
+    // (RayTracer::doDaRayTracingShizz): rgb8 w*h*3, depth8 w*h grey values of depth.bmp,
+    // blurred8 (w-12)*(h-12)*3.  A writer uses the bytes when they are set, else the floats.
+    const uint8_t *rgb8 = nullptr, *depth8 = nullptr, *blurred8 = nullptr;
     // imageWriter.h:239: the byte buffer the three BMP writers share; what one writer leaves
     // in it shows through in the next file where that one skips bytes
     mutable std::vector<unsigned char> imageC;
@@ -119,7 +123,13 @@ public:
     RayTracer(const double modelview[16], int width, int height);
     // main.cpp:322: renders and writes result.ppm, result.bmp, depth.bmp and
     // blurred.bmp into out_dir; returns the seconds the frame took, < 0 on error.
-    double doDaRayTracingShizz(const char* out_dir = ".");
+    // The frame, both depth normalisations and the blur stay on the GPU; what comes back is
+    // the 8-bit planes of the four files (result.rgb8 / depth8 / blurred8).  floatPlanes = true
+    // brings the float planes back instead (result.rgb / depth / blurred as the reference's
+    // Image holds them) and post-processes those.  rowUpdates = true also writes the blank
+    // result.bmp first and rewrites it row by row (main.cpp:325, 407) before the final files.
+    double doDaRayTracingShizz(const char* out_dir = ".", bool floatPlanes = false, bool rowUpdates = false);
+    double files_seconds = 0; // time the last call spent writing files
     // Key 'f' (raytracing.cpp:504-507): focusDepth = depth of what the ray through pixel (x, y)
     // hits, traced as performRayTracing(origin, dest, 0, 0.0f, focusDepth); the ray is the one
     // raytrace() builds for that pixel (main.cpp:514-529).  Returns false when the GPU call fails.

@@ -69,7 +69,7 @@ extern "C" void rt_default_params(RtParams* p, int32_t width, int32_t height)
 #define RT_BLOCK 256
 
 __device__ __forceinline__ void flush_counters(DCounters* ctr, unsigned nc, unsigned ns, unsigned nt,
-                                               unsigned nn, unsigned ncam)
+                                               unsigned nn, unsigned ncam, unsigned nsh = 0, unsigned nch = 0)
 {
     // one atomic per wave and counter
     for (int off = 32; off > 0; off >>= 1) {
@@ -78,6 +78,8 @@ __device__ __forceinline__ void flush_counters(DCounters* ctr, unsigned nc, unsi
         nt += __shfl_down(nt, off);
         nn += __shfl_down(nn, off);
         ncam += __shfl_down(ncam, off);
+        nsh += __shfl_down(nsh, off);
+        nch += __shfl_down(nch, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&ctr->rays_closest, (unsigned long long)nc);
@@ -85,6 +87,8 @@ __device__ __forceinline__ void flush_counters(DCounters* ctr, unsigned nc, unsi
         atomicAdd(&ctr->tri_tests, (unsigned long long)nt);
         atomicAdd(&ctr->node_visits, (unsigned long long)nn);
         atomicAdd(&ctr->camera_rays, (unsigned long long)ncam);
+        if (nsh) atomicAdd(&ctr->shaded_hits, (unsigned long long)nsh);
+        if (nch) atomicAdd(&ctr->child_rays, (unsigned long long)nch);
     }
 }
 
@@ -128,7 +132,7 @@ k_trace_rays(DScene S, DParams P, int k0, float prev_ni, long long n, const floa
 {
     extern __shared__ uint2 s_stack[];
     const long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0, nsh = 0, nch = 0;
     if (i < n) {
         const f3 o = mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
         const f3 d = mk3(dst[3 * i], dst[3 * i + 1], dst[3 * i + 2]);
@@ -136,12 +140,12 @@ k_trace_rays(DScene S, DParams P, int k0, float prev_ni, long long n, const floa
         float    mt;
         int      ft;
         ncam = 1;
-        trace_sample(S, P, o, d, k0, prev_ni, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+        trace_sample(S, P, o, d, k0, prev_ni, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
         rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
         if (minT) minT[i] = mt;
         if (tri) tri[i] = ft;
     }
-    flush_counters(ctr, nc, ns, nt, nn, ncam);
+    flush_counters(ctr, nc, ns, nt, nn, ncam, nsh, nch);
 }
 
 // Pixel-centre ray of every pixel slot.  MSAA == 1: the whole sample, pixel
@@ -155,7 +159,7 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
 {
     extern __shared__ uint2 s_stack[];
     const long long slot = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0, nsh = 0, nch = 0;
     int             x, y;
     if (slot < n_slots && slot_to_pixel(P, slot, x, y)) {
         f3 o, d;
@@ -166,7 +170,7 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
             f3    c;
             float mt;
             int   ft;
-            trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+            trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
             rgb[3 * p] = clamp01(c.x), rgb[3 * p + 1] = clamp01(c.y), rgb[3 * p + 2] = clamp01(c.z);
             depth[p] = mt; // FLT_MAX on a miss (main.cpp:442-443)
             if (tri) tri[p] = ft;
@@ -183,7 +187,7 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
             }
         }
     }
-    flush_counters(ctr, nc, ns, nt, nn, ncam);
+    flush_counters(ctr, nc, ns, nt, nn, ncam, nsh, nch);
 }
 
 __constant__ float c_msaa4[4][2] = {{-1.f / 8, -3.f / 8}, {3.f / 8, -1.f / 8}, {-3.f / 8, 1.f / 8},
@@ -207,7 +211,7 @@ k_samples(DScene S, DParams P, long long n_slots, const unsigned char* __restric
     const long long idx = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
     const int       s = (int)(idx / n_slots);
     const long long slot = idx - (long long)s * n_slots;
-    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0;
+    unsigned        nt = 0, nn = 0, nc = 0, ns = 0, ncam = 0, nsh = 0, nch = 0;
     int             x, y;
     if (s < P.msaa && hit_flag[slot] && slot_to_pixel(P, slot, x, y)) {
         const float ox = P.msaa == 4 ? c_msaa4[s][0] : c_msaa16[s][0];
@@ -217,10 +221,10 @@ k_samples(DScene S, DParams P, long long n_slots, const unsigned char* __restric
         float mt;
         int   ft;
         ncam = 1;
-        trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn);
+        trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
         samples[slot * P.msaa + s] = make_float4(c.x, c.y, c.z, mt);
     }
-    flush_counters(ctr, nc, ns, nt, nn, ncam);
+    flush_counters(ctr, nc, ns, nt, nn, ncam, nsh, nch);
 }
 
 // main.cpp:449-507: ordered sum of the samples, divided by their number;
@@ -420,6 +424,17 @@ __global__ void k_quantize(const float* __restrict__ v, long long n, unsigned ch
     out[i] = (unsigned char)q;
 }
 
+// depth.bmp's grey value, imageWriter.h:387: (unsigned char)((1 - depth) * 255.0f)
+__global__ void k_depth_grey(const float* __restrict__ depthN, long long n, unsigned char* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = (1 - depthN[i]) * 255.0f;
+    int         q = 0;
+    if (x == x && x < 2147483648.0f && x >= -2147483648.0f) q = (int)x;
+    out[i] = (unsigned char)q;
+}
+
 __global__ void k_pack_tiles(DParams P, long long n_slots, const float* __restrict__ rgb,
                              const float* __restrict__ depth, float4* payload)
 {
@@ -484,6 +499,10 @@ struct RtScene {
     hipEvent_t  wf_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t  wf_fork = nullptr;
     size_t     wf_mem_bytes = 0;
+    // frame buffers of rt_render_result_planes: device planes + pinned host bytes, grown on demand
+    void*  d_frame = nullptr;
+    void*  h_frame = nullptr;
+    size_t frame_px = 0;
     // optional per-kernel timing (rt_scene_set_timing)
     bool                                 timing = false;
     std::vector<hipEvent_t>              ev_pool; // pairs
@@ -538,6 +557,8 @@ extern "C" void rt_scene_destroy(RtScene* s)
                     s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    if (s->h_frame) (void)hipHostFree(s->h_frame);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -1094,6 +1115,8 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
     st->tri_tests = c.tri_tests;
     st->node_visits = c.node_visits;
     st->camera_rays = c.camera_rays;
+    st->shaded_hits = c.shaded_hits;
+    st->child_rays = c.child_rays;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
     st->kernel_ms = ms;
@@ -1448,7 +1471,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             for (int k = 0; k < live; ++k) {
                 hipStream_t st = s->wf_stream[k];
                 if (level > 0 || !traced0) wf_launch_trace(s, V[k], q, &V[k].ctr->head_rays[level], st);
-                hipLaunchKernelGGL(k_wf_shade, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level);
+                hipLaunchKernelGGL(k_wf_shade, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level, s->d_ctr);
                 // work lists of the next level's rays (block 0) and of this level's shadow queues
                 hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, V[k], q ^ 1,
                                    P.n_lights);
@@ -1758,6 +1781,63 @@ extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, 
         return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, 12 * nout, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// The 'r' path with the frame kept on the device: render, both normalisations and the blur,
+// then the three 8-bit planes the writers put into result.ppm/.bmp, depth.bmp and blurred.bmp
+// (58 MB for a 4K frame instead of 166 MB of float planes), copied into pinned host memory the
+// scene owns.  Frame buffers and the pinned block are allocated once per frame size.
+extern "C" int rt_render_result_planes(RtScene* s, const float camera[24], const float* lights, int32_t n_lights,
+                                       const RtParams* params, const uint8_t** rgb8, const uint8_t** depth8,
+                                       const uint8_t** blurred8, RtStats* stats)
+{
+    if (!s || !params || !rgb8 || !depth8 || !blurred8)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes: null argument");
+    const int W = params->width, H = params->height;
+    if (W < 2 || H < 2 || W > 32768 || H > 32768)
+        return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", W, H);
+    if (params->tile_w != 0 || params->tile_h != 0)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes renders whole frames (tile_w = tile_h = 0)");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)W * H;
+    const bool   blur = W > 12 && H > 12;
+    const size_t nbl = blur ? (size_t)(W - 12) * (H - 12) : 0;
+    // device: rgb f32 | depth f32 | blurred f32 | rgb8 | depth8 | blurred8 (each part 256-byte aligned)
+    const size_t o_depth = align256(12 * npx), o_blur = o_depth + align256(4 * npx),
+                 o_rgb8 = o_blur + align256(12 * nbl + 16), o_depth8 = o_rgb8 + align256(3 * npx),
+                 o_blur8 = o_depth8 + align256(npx), total = o_blur8 + align256(3 * nbl + 16);
+    const size_t h_depth8 = align256(3 * npx), h_blur8 = h_depth8 + align256(npx), h_total = h_blur8 + align256(3 * nbl + 16);
+    if (s->frame_px != npx) {
+        if (s->d_frame) (void)hipFree(s->d_frame);
+        if (s->h_frame) (void)hipHostFree(s->h_frame);
+        s->d_frame = s->h_frame = nullptr, s->frame_px = 0;
+        HIP_TRY(hipMalloc(&s->d_frame, total));
+        HIP_TRY(hipHostMalloc(&s->h_frame, h_total, hipHostMallocDefault));
+        s->frame_px = npx;
+    }
+    unsigned char* d = (unsigned char*)s->d_frame;
+    unsigned char* h = (unsigned char*)s->h_frame;
+    float*         d_rgb = (float*)d, *d_depth = (float*)(d + o_depth), *d_blur = (float*)(d + o_blur);
+    int rc = rt_render_frame_device(s, camera, lights, n_lights, params, d_rgb, d_depth, nullptr, nullptr, stats);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * npx, 256)), dim3(256), 0, 0, (const float*)d_rgb,
+                       (long long)(3 * npx), d + o_rgb8);
+    HIP_TRY(hipMemcpyAsync(h, d + o_rgb8, 3 * npx, hipMemcpyDeviceToHost, 0));
+    if ((rc = rt_postprocess_device(s->device, W, H, params->focusDepth, params->depthPower, d_rgb, d_depth,
+                                    blur ? d_blur : nullptr, nullptr)))
+        return rc;
+    hipLaunchKernelGGL(k_depth_grey, dim3(blocks_for(npx, 256)), dim3(256), 0, 0, (const float*)d_depth, (long long)npx,
+                       d + o_depth8);
+    HIP_TRY(hipMemcpyAsync(h + h_depth8, d + o_depth8, npx, hipMemcpyDeviceToHost, 0));
+    if (blur) {
+        hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * nbl, 256)), dim3(256), 0, 0, (const float*)d_blur,
+                           (long long)(3 * nbl), d + o_blur8);
+        HIP_TRY(hipMemcpyAsync(h + h_blur8, d + o_blur8, 3 * nbl, hipMemcpyDeviceToHost, 0));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    *rgb8 = h, *depth8 = h + h_depth8, *blurred8 = blur ? h + h_blur8 : nullptr;
     return RT_OK;
 }
 

@@ -73,6 +73,7 @@ struct DParams {
 
 struct DCounters {
     unsigned long long rays_closest, rays_shadow, tri_tests, node_visits, camera_rays;
+    unsigned long long shaded_hits, child_rays;
 };
 
 struct f3 {
@@ -326,7 +327,8 @@ struct PendingRay {
 __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, f3 origin, f3 dest,
                                              int k0, float prev_ni, uint2* stk, int stride, f3& rgb, float& minT_out,
                                              int& tri_out, unsigned& n_closest, unsigned& n_shadow,
-                                             unsigned& n_tests, unsigned& n_nodes)
+                                             unsigned& n_tests, unsigned& n_nodes, unsigned& n_shaded,
+                                             unsigned& n_child)
 {
     PendingRay pend[RT_MAX_PENDING];
     int        np = 1;
@@ -350,6 +352,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
             acc = acc + mk3(P.bg[0], P.bg[1], P.bg[2]) * r.w;
             continue;
         }
+        ++n_shaded;
         const f3     dir = r.d - r.o;
         const f3     hp = r.o + dir * hit.t; // raytracing.cpp:384
         const float4 s0 = S.tri_shade[3 * orig], s1 = S.tri_shade[3 * orig + 1],
@@ -406,6 +409,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
         if (illum == 3) { // raytracing.cpp:177-197
             const f3 refl = dir - N * (2.0f * dot3(N, dir));
             acc = acc + res * (0.5f * r.w);
+            ++n_child;
             PendingRay& c = pend[np++];
             c.o = hp + refl * 0.001f, c.d = hp + refl, c.w = 0.5f * r.w, c.ni = n2, c.k = newK;
             continue;
@@ -429,6 +433,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                 wLocal += 0.1f * (1.0f - rf);
                 const float wT = 0.9f * (1.0f - rf) * r.w;
                 if (wT != 0.0f) {
+                    ++n_child;
                     PendingRay& c = pend[np++];
                     c.o = hp + tRay * 0.001f, c.d = hp + tRay, c.w = wT, c.ni = n2, c.k = newK;
                 }
@@ -436,6 +441,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
             const float wR = 0.5f * rf * r.w;
             if (wR != 0.0f) {
                 const f3    refRay = I - N * (2.0f * dot3(I, N));
+                ++n_child;
                 PendingRay& c = pend[np++];
                 c.o = hp + refRay * 0.001f, c.d = hp + refRay, c.w = wR, c.ni = n2, c.k = newK;
             }

@@ -429,7 +429,8 @@ __device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lig
 // shade: one block per region, one thread per ray of level `level`
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& P, const WfBuffers& B,
-                                                const WfRays in, const WfRays out, int r, WfShared* sh)
+                                                const WfRays in, const WfRays out, int r, WfShared* sh,
+                                                unsigned& n_shaded, unsigned& n_child)
 {
     int&         s_child = sh->child;
     int*         s_sh = sh->sh;
@@ -459,7 +460,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
         const bool is_hit = valid && orig >= 0;
         if (valid && !is_hit) // raytracing.cpp:74
             wf_acc_add(B, meta.x, mk3(P.bg[0], P.bg[1], P.bg[2]) * w, shared);
-        if (is_hit) wf_surface(S, o, dst, hit, s);
+        if (is_hit) wf_surface(S, o, dst, hit, s), ++n_shaded;
         // ---- shadow rays, one queue per light ----
         float shadowMax = 0.0f;
         for (int li = 0; li < P.n_lights; ++li) {
@@ -531,6 +532,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
             }
         }
         if (valid) B.wlocal[i] = wl;
+        n_child += nchild;
         for (int c = 0; c < 2; ++c) {
             const bool mine = c < nchild;
             const int  pos = wf_append(&s_child, mine);
@@ -548,10 +550,16 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
 }
 
 __global__ void __launch_bounds__(WF_BLOCK)
-k_wf_shade(DScene S, DParams P, WfBuffers B, int level)
+k_wf_shade(DScene S, DParams P, WfBuffers B, int level, DCounters* ctr)
 {
     __shared__ WfShared sh;
-    wf_shade_region(S, P, B, B.rays[level & 1], B.rays[(level + 1) & 1], blockIdx.x, &sh);
+    unsigned            n_shaded = 0, n_child = 0;
+    wf_shade_region(S, P, B, B.rays[level & 1], B.rays[(level + 1) & 1], blockIdx.x, &sh, n_shaded, n_child);
+    for (int s = 32; s > 0; s >>= 1) n_shaded += __shfl_down(n_shaded, s), n_child += __shfl_down(n_child, s);
+    if ((threadIdx.x & 63) == 0 && (n_shaded | n_child)) {
+        atomicAdd(&ctr->shaded_hits, (unsigned long long)n_shaded);
+        atomicAdd(&ctr->child_rays, (unsigned long long)n_child);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -874,7 +882,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
     extern __shared__ __align__(16) unsigned char s_mem[];
     __shared__ WfShared sh;
     const WfStack       stk = wf_stack(S, s_mem);
-    unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0;
+    unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0, n_shaded = 0, n_child = 0;
     const size_t        ns = (size_t)B.n_samples;
     for (;;) {
         __syncthreads();
@@ -909,7 +917,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         WF_TL(2);
         // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
         if (B.rays[q].cnt[r] > 0) {
-            wf_shade_region(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh);
+            wf_shade_region(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh, n_shaded, n_child);
             __syncthreads();
             for (int level = 0; level < 5; ++level, q ^= 1) {
                 const WfRays in = B.rays[q], out = B.rays[q ^ 1];
@@ -920,7 +928,7 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
                 wf_resolve_region(S, P, B, in, r);
                 if (n_out == 0) break;
                 __syncthreads(); // resolve still reads the queue the next shade writes its children to
-                wf_shade_region(S, P, B, out, in, r, &sh);
+                wf_shade_region(S, P, B, out, in, r, &sh, n_shaded, n_child);
                 __syncthreads();
                 WF_TL(4 + 2 * level);
             }
@@ -944,5 +952,12 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         atomicAdd(&ctr->node_visits, (unsigned long long)n_nodes);
         atomicAdd(&ctr->rays_closest, (unsigned long long)n_closest);
         atomicAdd(&ctr->rays_shadow, (unsigned long long)n_shadow);
+    }
+    if (COUNT) { // the timed variant leaves these two out
+        for (int s = 32; s > 0; s >>= 1) n_shaded += __shfl_down(n_shaded, s), n_child += __shfl_down(n_child, s);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctr->shaded_hits, (unsigned long long)n_shaded);
+            atomicAdd(&ctr->child_rays, (unsigned long long)n_child);
+        }
     }
 }

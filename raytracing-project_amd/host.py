@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librt_host.so")
 EXPORTS = ["rth_scene_load", "rth_scene_free", "rth_scene_desc", "rth_tree_depth",
            "rth_material_name", "rth_read_camera_sav", "rth_camera_corners", "rth_write_ppm",
            "rth_write_bmp", "rth_write_depth_bmp", "rth_write_blurred_bmp", "rth_render_to_files",
-           "rth_last_error", "rth_decode_png", "rth_render_to_files_focus", "rth_write_result_files"]
+           "rth_last_error", "rth_decode_png", "rth_render_to_files_focus", "rth_write_result_files", "rth_render_to_files_float",
+           "rth_time_r_path"]
 
 _lib = None
 
@@ -46,6 +47,11 @@ def lib():
     L.rth_render_to_files.restype = C.c_double
     L.rth_render_to_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                       C.c_int, C.POINTER(capi.RtStats)]
+    L.rth_render_to_files_float.restype = C.c_double
+    L.rth_render_to_files_float.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                            C.c_int]
+    L.rth_time_r_path.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                  C.POINTER(C.c_double)]
     L.rth_last_error.restype = C.c_char_p
     L.rth_render_to_files_focus.restype = C.c_double
     L.rth_render_to_files_focus.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
@@ -199,6 +205,28 @@ def render_to_files(obj_path, camera_sav, W, H, msaa, out_dir, device=0):
     if secs < 0:
         raise RuntimeError(lib().rth_last_error().decode(errors="replace"))
     return secs, st
+
+
+def render_to_files_float(obj_path, camera_sav, W, H, msaa, out_dir, device=0, row_updates=False):
+    """The 'r' path through the float planes (as the reference's Image holds them)."""
+    secs = lib().rth_render_to_files_float(os.fsencode(obj_path), os.fsencode(camera_sav), W, H, msaa,
+                                           os.fsencode(out_dir), device, 1 if row_updates else 0)
+    if secs < 0:
+        raise RuntimeError(lib().rth_last_error().decode(errors="replace"))
+    return secs
+
+
+def time_r_path(obj_path, camera_sav, W, H, msaa, out_dir, device=0, runs=2):
+    """Wall time of RayTracer::doDaRayTracingShizz on a resident scene (last of `runs`)."""
+    out = (C.c_double * 2)()
+    rc = lib().rth_time_r_path(os.fsencode(obj_path), os.fsencode(camera_sav), W, H, msaa, os.fsencode(out_dir),
+                               device, runs, out)
+    if rc != 0:
+        raise RuntimeError(lib().rth_last_error().decode(errors="replace"))
+    return {"frame_call_ms": round(out[0] * 1e3, 2), "file_writes_ms": round(out[1] * 1e3, 2),
+            "total_ms": round((out[0] + out[1]) * 1e3, 2),
+            "what": "frame_call = GPU frame + depth passes + blur + 8-bit planes to pinned host memory; "
+                    "file_writes = result.ppm, result.bmp, depth.bmp, blurred.bmp by the host writers"}
 
 
 def render_to_files_focus(obj_path, camera_sav, W, H, msaa, out_dir, fx, fy, device=0):

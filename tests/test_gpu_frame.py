@@ -174,6 +174,22 @@ def test_r_path_files_match_oracle_writers(P, oracle, tmp_path):
         assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.99, (f, d.max(), (d > 1).sum())
 
 
+def test_r_path_float_planes_and_row_updates(P, tmp_path):
+    """The 'r' path keeps the frame on the GPU and brings back 8-bit planes; the variant that
+    brings the float planes back (and rewrites result.bmp row by row first, main.cpp:325, 407)
+    must write the same four files, byte for byte - ragged width, so rows carry padding."""
+    name, W, H, msaa = "refractionballs", 150, 91, 4
+    obj, sav = os.path.join(SCENES, name + ".obj"), os.path.join(SCENES, "cameras", name + ".sav")
+    a, b = tmp_path / "bytes", tmp_path / "floats"
+    a.mkdir(), b.mkdir()
+    P.host.render_to_files(obj, sav, W, H, msaa, str(a))
+    P.host.render_to_files_float(obj, sav, W, H, msaa, str(b), row_updates=True)
+    for f in ("result.ppm", "result.bmp", "depth.bmp", "blurred.bmp"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    t = P.host.time_r_path(obj, sav, W, H, msaa, str(a), runs=2)
+    assert t["frame_call_ms"] > 0 and t["file_writes_ms"] > 0
+
+
 def test_focus_pick_then_r_path(P, oracle, tmp_path):
     """Key 'f' over a pixel, then 'r': a focus depth other than 0 makes the two depth
     normalisations differ (imageWriter.h:124-135, 352, 416); files against the oracle's."""

@@ -147,7 +147,7 @@ def test_struct_sizes_match_header(P):
     assert C.sizeof(P.capi.RtMaterial) == 64
     assert C.sizeof(P.capi.RtKdNode) == 40
     assert C.sizeof(P.capi.RtParams) == 68
-    assert C.sizeof(P.capi.RtStats) == 48
+    assert C.sizeof(P.capi.RtStats) == 64
 
 
 def test_errors_without_a_gpu(P):
