@@ -277,7 +277,27 @@ def main():
     gs = slots[0]["gs"]
     rgb, depth = slots[0]["rgb"], slots[0]["depth"]
     PER_RANK = 16   # shares per GPU in the deal; rank 0 may own fewer (it also runs the post-process)
-    state = {}
+    state = {"gather": "none (1 GPU)" if world == 1 else "torch.distributed.gather"}
+
+    # The gather of the tile payloads goes through the library's own RCCL entry point
+    # (rt_gather_tiles_rccl: grouped ncclRecv on rank 0 / ncclSend elsewhere, on the frame's
+    # stream) with a communicator of its own; the unique id travels over the process group.
+    # RT_BENCH_GATHER=torch keeps torch.distributed.gather.
+    comm = C.c_void_p()
+    if world > 1 and backend == "nccl" and os.environ.get("RT_BENCH_GATHER", "rccl") == "rccl":
+        try:
+            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                capi.check(L.rt_rccl_unique_id(buf))
+                ident.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+            dist.broadcast(ident, src=0)
+            raw = (C.c_ubyte * 128)(*ident.cpu().tolist())
+            capi.check(L.rt_rccl_comm_create(raw, world, rank, local, C.byref(comm)))
+            state["gather"] = "rt_gather_tiles_rccl"
+        except Exception as e:  # noqa: BLE001 - reported in the line, the torch gather takes over
+            state["gather"] = f"torch.distributed.gather (rt_rccl_comm_create failed: {e})"
+            comm = C.c_void_p()
 
     def set_deal(first_rank_shares):
         """Tiles are dealt over n_shares = first_rank_shares + 16 (N - 1) shares; rank r renders
@@ -287,8 +307,17 @@ def main():
         p.world = n_shares
         n_slots = L.rt_tile_pixels(C.byref(p), p.rank)
         state.update(deal=(n_shares, deal), first_rank_shares=deal[0][1])
+        per_rank = []
+        for first, span in deal:
+            pr = capi.RtParams.from_buffer_copy(p)
+            pr.rank, pr.rank_span = first, span
+            per_rank.append(int(L.rt_tile_pixels(C.byref(pr), pr.rank)) * 4)
+        state["floats_per_rank"] = (C.c_int64 * world)(*per_rank)
+        state["offsets"] = [sum(per_rank[:r]) for r in range(world)]
         for sl in slots:
             sl["payload"] = torch.zeros((max(n_slots, 1), 4), dtype=torch.float32, device=dev)[:n_slots]
+            sl["gathered"] = torch.zeros(max(sum(per_rank), 4) if rank == 0 else 4, dtype=torch.float32,
+                                         device=dev)
 
     set_deal(PER_RANK)
 
@@ -313,6 +342,15 @@ def main():
                 if backend == "gloo":
                     pkg.distributed.gather_frame(payload.cpu(), W, H, TILE, TILE, rank, world, dist,
                                                  lambda src, buf: unpack(src, buf.to(dev)), state["deal"])
+                elif state["gather"] == "rt_gather_tiles_rccl":
+                    capi.check(L.rt_gather_tiles_rccl(comm, rank, world, C.c_void_p(payload.data_ptr()),
+                                                      state["floats_per_rank"],
+                                                      C.c_void_p(sl["gathered"].data_ptr()), C.c_void_p(stream)))
+                    if rank == 0:
+                        for src in range(world):
+                            n_f = state["floats_per_rank"][src]
+                            if n_f:
+                                unpack(src, sl["gathered"][state["offsets"][src]:state["offsets"][src] + n_f])
                 else:
                     pkg.distributed.gather_frame(payload, W, H, TILE, TILE, rank, world, dist, unpack,
                                                  state["deal"])
@@ -373,6 +411,21 @@ def main():
                      "post_ms": round(t_post, 3)}
         shares0 = bcast_int(min(max(shares0, 1), PER_RANK))
         set_deal(shares0)
+
+    if state["gather"] == "rt_gather_tiles_rccl":
+        # both gathers once, outside the timed region: the frames rank 0 rebuilds must be equal
+        frame()
+        torch.cuda.synchronize()
+        mine = (slots[0]["rgb"].clone(), slots[0]["depth"].clone()) if rank == 0 else None
+        state["gather"] = "torch.distributed.gather"
+        frame()
+        torch.cuda.synchronize()
+        same = 1
+        if rank == 0:
+            same = int(torch.equal(mine[0], slots[0]["rgb"]) and torch.equal(mine[1], slots[0]["depth"]))
+        same = bcast_int(same)
+        state["gather"] = "rt_gather_tiles_rccl" if same else \
+            "torch.distributed.gather (rt_gather_tiles_rccl rebuilt a different frame)"
 
     # one counted frame: rays this rank traces per frame (deterministic)
     st = frame(0, stats=True)
@@ -459,7 +512,7 @@ def main():
                                    "reflection/refraction depth 5",
                        "partition": (f"{TILE}x{TILE} tiles dealt over {state['deal'][0]} shares: rank 0 renders "
                                      f"{state['first_rank_shares']}, every other rank {PER_RANK} (rank 0 also runs the "
-                                     "post-process); RCCL gather to rank 0") if world > 1
+                                     "post-process); gather to rank 0: " + state["gather"]) if world > 1
                        else f"{TILE}x{TILE} tiles, 1 GPU",
                        "rays_per_frame": int(rays_per_frame),
                        "tri_tests_per_ray": round(tests_per_frame / rays_per_frame, 2),

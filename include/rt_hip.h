@@ -260,6 +260,32 @@ int     rt_pack_tiles_device(int device, const RtParams *params, const float *d_
 int     rt_unpack_tiles_device(int device, const RtParams *params, int32_t src_rank,
                                const float *d_payload, float *d_rgb, float *d_depth, void *stream);
 
+/* The exchange step of a frame shared by several GPUs, one process per GPU: every rank's tile
+ * payload (rt_pack_tiles_device) is gathered on rank 0 over RCCL - ncclGroupStart, one ncclRecv
+ * per peer on rank 0 / one ncclSend on every other rank, ncclGroupEnd - so each peer uses its own
+ * xGMI link to rank 0.  It replaces the shared Image the reference's threads write into
+ * (main.cpp:329-339, 404).  comm is an ncclComm_t, from rt_rccl_comm_create or the caller's own.
+ * floats_per_rank[r] = rt_tile_pixels(params of rank r) * 4; on rank 0 d_gathered receives the
+ * payloads one after the other in rank order (d_gathered may be NULL elsewhere).  Enqueued on
+ * `stream`; RCCL is loaded on first use (librccl.so.1), RT_ERR_UNSUPPORTED if it is not there. */
+#define RT_RCCL_ID_BYTES 128
+int  rt_rccl_unique_id(void *id128);            /* ncclGetUniqueId, on rank 0; hand the bytes to every rank */
+int  rt_rccl_comm_create(const void *id128, int32_t n_ranks, int32_t rank, int device, void **comm);
+void rt_rccl_comm_destroy(void *comm);
+int  rt_gather_tiles_rccl(void *comm, int32_t rank, int32_t n_ranks, const float *d_payload,
+                          const int64_t *floats_per_rank, float *d_gathered, void *stream);
+
+/* rt_render_result_planes for a frame shared by n_ranks processes, one per GPU (the C++ host's
+ * replacement of the thread bands of main.cpp:329-339): this rank renders its 32 x 32 tiles
+ * (dealt round-robin, tile t to rank t % n_ranks), the payloads are gathered on rank 0
+ * (rt_gather_tiles_rccl), and rank 0 rebuilds the frame, post-processes it and receives the
+ * planes; on the other ranks the three pointers come back NULL.  n_ranks == 1 needs no
+ * communicator.  Every rank calls it with the same camera, lights and params. */
+int rt_render_result_planes_shared(RtScene *scene, void *comm, int32_t rank, int32_t n_ranks,
+                                   const float camera[24], const float *lights, int32_t n_lights,
+                                   const RtParams *params, const uint8_t **rgb8, const uint8_t **depth8,
+                                   const uint8_t **blurred8, RtStats *stats);
+
 #ifdef __cplusplus
 }
 #endif

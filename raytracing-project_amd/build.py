@@ -39,7 +39,7 @@ def build_hip(force=False):
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
         os.path.join(ROOT, "include", "rt_hip.h")]
     if force or _newer(out, src):
-        subprocess.check_call([hipcc(), *HIP_FLAGS, "-shared", src[0], "-o", out])
+        subprocess.check_call([hipcc(), *HIP_FLAGS, "-shared", src[0], "-o", out, "-ldl"])
     return out
 
 

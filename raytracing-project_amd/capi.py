@@ -81,6 +81,8 @@ EXPORTS = [
     "rt_scene_info", "rt_scene_set_timing", "rt_scene_collect_timing", "rt_check_hits", "rt_trace_rays", "rt_render_frame", "rt_render_frame_device", "rt_render_result_planes",
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
     "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
+    "rt_rccl_unique_id", "rt_rccl_comm_create", "rt_rccl_comm_destroy", "rt_gather_tiles_rccl",
+    "rt_render_result_planes_shared",
 ]
 
 _lib = None
@@ -134,6 +136,13 @@ def lib():
     L.rt_tile_pixels.restype = I64
     L.rt_pack_tiles_device.argtypes = [C.c_int, C.POINTER(RtParams), P, P, P, P]
     L.rt_unpack_tiles_device.argtypes = [C.c_int, C.POINTER(RtParams), I32, P, P, P, P]
+    L.rt_render_result_planes_shared.argtypes = [P, P, I32, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(P),
+                                                 C.POINTER(P), C.POINTER(P), C.POINTER(RtStats)]
+    L.rt_rccl_unique_id.argtypes = [P]
+    L.rt_rccl_comm_create.argtypes = [P, I32, I32, C.c_int, C.POINTER(P)]
+    L.rt_rccl_comm_destroy.argtypes = [P]
+    L.rt_rccl_comm_destroy.restype = None
+    L.rt_gather_tiles_rccl.argtypes = [P, I32, I32, P, C.POINTER(I64), P, P]
     _lib = L
     return L
 

@@ -169,12 +169,18 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir, bool floatPlanes, boo
     std::vector<float> l = lightArray();
     const auto         t0 = std::chrono::steady_clock::now();
     result.rgb8 = result.depth8 = result.blurred8 = nullptr;
+    if (n_ranks_ > 1 && floatPlanes) {
+        g_error = "doDaRayTracingShizz: a shared frame comes back as 8-bit planes only";
+        return -1.0;
+    }
     if (!floatPlanes) {
-        if (rt_render_result_planes(g_scene, corners, l.data(), (int32_t)MyLightPositions.size(), &p, &result.rgb8,
-                                    &result.depth8, &result.blurred8, &stats) != RT_OK) {
-            fail("rt_render_result_planes");
+        if (rt_render_result_planes_shared(g_scene, comm_, rank_, n_ranks_, corners, l.data(),
+                                           (int32_t)MyLightPositions.size(), &p, &result.rgb8, &result.depth8,
+                                           &result.blurred8, &stats) != RT_OK) {
+            fail("rt_render_result_planes_shared");
             return -1.0;
         }
+        if (rank_ != 0) return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } else {
         if (rt_render_frame(g_scene, corners, l.data(), (int32_t)MyLightPositions.size(), &p, result.rgb.data(),
                             result.depth.data(), nullptr, &stats) != RT_OK) {

@@ -130,6 +130,16 @@ public:
     // result.bmp first and rewrites it row by row (main.cpp:325, 407) before the final files.
     double doDaRayTracingShizz(const char* out_dir = ".", bool floatPlanes = false, bool rowUpdates = false);
     double files_seconds = 0; // time the last call spent writing files
+    // Several GPUs, one process each: every process calls shareFrame with its rank and a
+    // communicator from rt_rccl_comm_create before doDaRayTracingShizz; each then renders its
+    // tiles, rank 0 gathers them, post-processes and writes the files, the others write nothing.
+    void shareFrame(void* comm, int rank, int n_ranks) { comm_ = comm, rank_ = rank, n_ranks_ = n_ranks; }
+
+private:
+    void* comm_ = nullptr;
+    int   rank_ = 0, n_ranks_ = 1;
+
+public:
     // Key 'f' (raytracing.cpp:504-507): focusDepth = depth of what the ray through pixel (x, y)
     // hits, traced as performRayTracing(origin, dest, 0, 0.0f, focusDepth); the ray is the one
     // raytrace() builds for that pixel (main.cpp:514-529).  Returns false when the GPU call fails.

@@ -1,6 +1,8 @@
 // rt_api.hip - kernels and the extern "C" layer of librt_hip.so (see
 // include/rt_hip.h).  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -500,9 +502,12 @@ struct RtScene {
     hipEvent_t  wf_fork = nullptr;
     size_t     wf_mem_bytes = 0;
     // frame buffers of rt_render_result_planes: device planes + pinned host bytes, grown on demand
-    void*  d_frame = nullptr;
-    void*  h_frame = nullptr;
-    size_t frame_px = 0;
+    void*       d_frame = nullptr;
+    void*       h_frame = nullptr;
+    size_t      frame_px = 0;
+    hipStream_t frame_stream = nullptr;
+    void*       d_share = nullptr; // tile payload of this rank (+ the gathered payloads on rank 0)
+    size_t      share_bytes = 0;
     // optional per-kernel timing (rt_scene_set_timing)
     bool                                 timing = false;
     std::vector<hipEvent_t>              ev_pool; // pairs
@@ -559,6 +564,8 @@ extern "C" void rt_scene_destroy(RtScene* s)
         if (p) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->h_frame) (void)hipHostFree(s->h_frame);
+    if (s->d_share) (void)hipFree(s->d_share);
+    if (s->frame_stream) (void)hipStreamDestroy(s->frame_stream);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -1788,17 +1795,20 @@ extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, 
 // then the three 8-bit planes the writers put into result.ppm/.bmp, depth.bmp and blurred.bmp
 // (58 MB for a 4K frame instead of 166 MB of float planes), copied into pinned host memory the
 // scene owns.  Frame buffers and the pinned block are allocated once per frame size.
-extern "C" int rt_render_result_planes(RtScene* s, const float camera[24], const float* lights, int32_t n_lights,
-                                       const RtParams* params, const uint8_t** rgb8, const uint8_t** depth8,
-                                       const uint8_t** blurred8, RtStats* stats)
+// With a communicator the frame is shared: this rank renders its tiles (32 x 32, dealt round-
+// robin), the payloads are gathered on rank 0, which rebuilds the frame and goes on alone.
+static int gather_rccl(void* comm, int rank, int n_ranks, const float* d_payload, const int64_t* floats_per_rank,
+                       float* d_gathered, hipStream_t st);
+
+static int render_planes_impl(RtScene* s, void* comm, int rank, int n_ranks, const float camera[24],
+                              const float* lights, int32_t n_lights, const RtParams* params, const uint8_t** rgb8,
+                              const uint8_t** depth8, const uint8_t** blurred8, RtStats* stats)
 {
-    if (!s || !params || !rgb8 || !depth8 || !blurred8)
-        return fail(RT_ERR_INVALID, "rt_render_result_planes: null argument");
     const int W = params->width, H = params->height;
     if (W < 2 || H < 2 || W > 32768 || H > 32768)
         return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", W, H);
     if (params->tile_w != 0 || params->tile_h != 0)
-        return fail(RT_ERR_INVALID, "rt_render_result_planes renders whole frames (tile_w = tile_h = 0)");
+        return fail(RT_ERR_INVALID, "the result planes are whole frames (tile_w = tile_h = 0); the library deals the tiles");
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)W * H;
     const bool   blur = W > 12 && H > 12;
@@ -1816,29 +1826,84 @@ extern "C" int rt_render_result_planes(RtScene* s, const float camera[24], const
         HIP_TRY(hipHostMalloc(&s->h_frame, h_total, hipHostMallocDefault));
         s->frame_px = npx;
     }
+    if (!s->frame_stream) HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+    hipStream_t    st = s->frame_stream;
     unsigned char* d = (unsigned char*)s->d_frame;
     unsigned char* h = (unsigned char*)s->h_frame;
     float*         d_rgb = (float*)d, *d_depth = (float*)(d + o_depth), *d_blur = (float*)(d + o_blur);
-    int rc = rt_render_frame_device(s, camera, lights, n_lights, params, d_rgb, d_depth, nullptr, nullptr, stats);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * npx, 256)), dim3(256), 0, 0, (const float*)d_rgb,
-                       (long long)(3 * npx), d + o_rgb8);
-    HIP_TRY(hipMemcpyAsync(h, d + o_rgb8, 3 * npx, hipMemcpyDeviceToHost, 0));
-    if ((rc = rt_postprocess_device(s->device, W, H, params->focusDepth, params->depthPower, d_rgb, d_depth,
-                                    blur ? d_blur : nullptr, nullptr)))
+    RtParams       p = *params;
+    int            rc;
+    if (n_ranks > 1) {
+        p.tile_w = p.tile_h = 32, p.world = n_ranks, p.rank = rank, p.rank_span = 1;
+        std::vector<int64_t> floats((size_t)n_ranks);
+        int64_t              all = 0;
+        for (int r = 0; r < n_ranks; ++r) floats[r] = rt_tile_pixels(&p, r) * 4, all += floats[r];
+        const size_t need = ((size_t)floats[rank] + (rank == 0 ? (size_t)all : 0)) * 4 + 512;
+        if (need > s->share_bytes) {
+            if (s->d_share) (void)hipFree(s->d_share);
+            s->d_share = nullptr, s->share_bytes = 0;
+            HIP_TRY(hipMalloc(&s->d_share, need));
+            s->share_bytes = need;
+        }
+        float* d_payload = (float*)s->d_share;
+        float* d_gathered = (float*)((unsigned char*)s->d_share + align256((size_t)floats[rank] * 4));
+        if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &p, d_rgb, d_depth, nullptr, st, stats))) return rc;
+        if ((rc = rt_pack_tiles_device(s->device, &p, d_rgb, d_depth, d_payload, st))) return rc;
+        if ((rc = gather_rccl(comm, rank, n_ranks, d_payload, floats.data(), d_gathered, st))) return rc;
+        if (rank != 0) {
+            HIP_TRY(hipStreamSynchronize(st));
+            *rgb8 = *depth8 = *blurred8 = nullptr;
+            return RT_OK;
+        }
+        int64_t off = floats[0];
+        for (int r = 1; r < n_ranks; ++r) { // rank 0's own tiles are in the frame already
+            if (floats[r] > 0 && (rc = rt_unpack_tiles_device(s->device, &p, r, d_gathered + off, d_rgb, d_depth, st)))
+                return rc;
+            off += floats[r];
+        }
+    } else if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &p, d_rgb, d_depth, nullptr, st, stats))) {
         return rc;
-    hipLaunchKernelGGL(k_depth_grey, dim3(blocks_for(npx, 256)), dim3(256), 0, 0, (const float*)d_depth, (long long)npx,
+    }
+    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * npx, 256)), dim3(256), 0, st, (const float*)d_rgb,
+                       (long long)(3 * npx), d + o_rgb8);
+    HIP_TRY(hipMemcpyAsync(h, d + o_rgb8, 3 * npx, hipMemcpyDeviceToHost, st));
+    if ((rc = rt_postprocess_device(s->device, W, H, params->focusDepth, params->depthPower, d_rgb, d_depth,
+                                    blur ? d_blur : nullptr, st)))
+        return rc;
+    hipLaunchKernelGGL(k_depth_grey, dim3(blocks_for(npx, 256)), dim3(256), 0, st, (const float*)d_depth, (long long)npx,
                        d + o_depth8);
-    HIP_TRY(hipMemcpyAsync(h + h_depth8, d + o_depth8, npx, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(hipMemcpyAsync(h + h_depth8, d + o_depth8, npx, hipMemcpyDeviceToHost, st));
     if (blur) {
-        hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * nbl, 256)), dim3(256), 0, 0, (const float*)d_blur,
+        hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * nbl, 256)), dim3(256), 0, st, (const float*)d_blur,
                            (long long)(3 * nbl), d + o_blur8);
-        HIP_TRY(hipMemcpyAsync(h + h_blur8, d + o_blur8, 3 * nbl, hipMemcpyDeviceToHost, 0));
+        HIP_TRY(hipMemcpyAsync(h + h_blur8, d + o_blur8, 3 * nbl, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(0));
+    HIP_TRY(hipStreamSynchronize(st));
     *rgb8 = h, *depth8 = h + h_depth8, *blurred8 = blur ? h + h_blur8 : nullptr;
     return RT_OK;
+}
+
+extern "C" int rt_render_result_planes(RtScene* s, const float camera[24], const float* lights, int32_t n_lights,
+                                       const RtParams* params, const uint8_t** rgb8, const uint8_t** depth8,
+                                       const uint8_t** blurred8, RtStats* stats)
+{
+    if (!s || !params || !rgb8 || !depth8 || !blurred8)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes: null argument");
+    return render_planes_impl(s, nullptr, 0, 1, camera, lights, n_lights, params, rgb8, depth8, blurred8, stats);
+}
+
+extern "C" int rt_render_result_planes_shared(RtScene* s, void* comm, int32_t rank, int32_t n_ranks,
+                                              const float camera[24], const float* lights, int32_t n_lights,
+                                              const RtParams* params, const uint8_t** rgb8, const uint8_t** depth8,
+                                              const uint8_t** blurred8, RtStats* stats)
+{
+    if (!s || !params || !rgb8 || !depth8 || !blurred8)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes_shared: null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes_shared: rank %d of %d", rank, n_ranks);
+    if (n_ranks > 1 && !comm) return fail(RT_ERR_INVALID, "rt_render_result_planes_shared: null communicator");
+    return render_planes_impl(s, comm, rank, n_ranks, camera, lights, n_lights, params, rgb8, depth8, blurred8, stats);
 }
 
 extern "C" int rt_quantize(int device, int64_t n, const float* v, uint8_t* out)
@@ -1898,5 +1963,136 @@ extern "C" int rt_unpack_tiles_device(int device, const RtParams* params, int32_
     hipLaunchKernelGGL(k_unpack_tiles, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, P,
                        n, (const float4*)d_payload, d_rgb, d_depth);
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// several GPUs: the gather of the tile payloads over RCCL
+// ---------------------------------------------------------------------------
+// RCCL is bound at run time (dlopen): a process that never shares a frame does not load it, and
+// a process that already holds a copy (PyTorch ships one under the same soname) uses that one.
+namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi    g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.ok) return RT_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(RT_ERR_UNSUPPORTED, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror());
+    bool all = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(h, name);
+        if (!p) all = false;
+        return p;
+    };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.Send = (decltype(g_rccl.Send))sym("ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))sym("ncclRecv");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!all) return fail(RT_ERR_UNSUPPORTED, "librccl.so.1 lacks a symbol the gather needs");
+    g_rccl.ok = true;
+    return RT_OK;
+}
+} // namespace
+
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(RT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));            \
+    } while (0)
+
+extern "C" int rt_rccl_unique_id(void* id128)
+{
+    if (!id128) return fail(RT_ERR_INVALID, "rt_rccl_unique_id: null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == RT_RCCL_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return RT_OK;
+}
+
+extern "C" int rt_rccl_comm_create(const void* id128, int32_t n_ranks, int32_t rank, int device, void** comm)
+{
+    if (!id128 || !comm) return fail(RT_ERR_INVALID, "rt_rccl_comm_create: null argument");
+    *comm = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(RT_ERR_INVALID, "rt_rccl_comm_create: rank %d of %d", rank, n_ranks);
+    int rc = check_device(device);
+    if (rc) return rc;
+    if ((rc = rccl_load())) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&c, n_ranks, id, rank));
+    *comm = (void*)c;
+    return RT_OK;
+}
+
+extern "C" void rt_rccl_comm_destroy(void* comm)
+{
+    if (comm && g_rccl.ok) (void)g_rccl.CommDestroy((ncclComm_t)comm);
+}
+
+extern "C" int rt_gather_tiles_rccl(void* comm, int32_t rank, int32_t n_ranks, const float* d_payload,
+                                    const int64_t* floats_per_rank, float* d_gathered, void* stream_)
+{
+    return gather_rccl(comm, rank, n_ranks, d_payload, floats_per_rank, d_gathered, (hipStream_t)stream_);
+}
+
+static int gather_rccl(void* comm, int rank, int n_ranks, const float* d_payload, const int64_t* floats_per_rank,
+                       float* d_gathered, hipStream_t st)
+{
+    if (!comm || !floats_per_rank) return fail(RT_ERR_INVALID, "rt_gather_tiles_rccl: null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(RT_ERR_INVALID, "rt_gather_tiles_rccl: rank %d of %d", rank, n_ranks);
+    int64_t total = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        if (floats_per_rank[r] < 0 || floats_per_rank[r] > ((int64_t)1 << 34))
+            return fail(RT_ERR_INVALID, "rt_gather_tiles_rccl: payload size of rank %d out of range", r);
+        total += floats_per_rank[r];
+    }
+    if (floats_per_rank[rank] > 0 && !d_payload) return fail(RT_ERR_INVALID, "rt_gather_tiles_rccl: null payload");
+    if (rank == 0 && total > 0 && !d_gathered) return fail(RT_ERR_INVALID, "rt_gather_tiles_rccl: null gather buffer on rank 0");
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (rank == 0) { // rank 0's own payload moves inside the device; every peer sends over its own xGMI link
+        if (floats_per_rank[0] > 0)
+            HIP_TRY(hipMemcpyAsync(d_gathered, d_payload, (size_t)floats_per_rank[0] * 4, hipMemcpyDeviceToDevice, st));
+        if (n_ranks == 1) return RT_OK;
+        RCCL_TRY(g_rccl.GroupStart());
+        int64_t off = floats_per_rank[0];
+        for (int r = 1; r < n_ranks; ++r) {
+            if (floats_per_rank[r] > 0)
+                RCCL_TRY(g_rccl.Recv(d_gathered + off, (size_t)floats_per_rank[r], ncclFloat, r, (ncclComm_t)comm, st));
+            off += floats_per_rank[r];
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    } else if (floats_per_rank[rank] > 0) {
+        RCCL_TRY(g_rccl.GroupStart());
+        RCCL_TRY(g_rccl.Send(d_payload, (size_t)floats_per_rank[rank], ncclFloat, 0, (ncclComm_t)comm, st));
+        RCCL_TRY(g_rccl.GroupEnd());
+    }
     return RT_OK;
 }

@@ -462,6 +462,42 @@ def test_rt_render_program(P, tmp_path):
     assert bad.returncode == 2 and "usage" in bad.stderr
 
 
+def test_rccl_layer_with_one_rank(P, tmp_path):
+    """What one GPU can exercise of the multi-GPU path in C: RCCL is found and bound, a
+    communicator of one rank is made, the gather of one rank is the copy of its payload, and
+    `rt_render --gpus 1` (the forked process per GPU) writes the files of the plain run."""
+    import subprocess
+
+    import torch
+    L = P.capi.lib()
+    ident = (C.c_ubyte * 128)()
+    P.capi.check(L.rt_rccl_unique_id(ident))
+    assert any(ident)
+    comm = C.c_void_p()
+    P.capi.check(L.rt_rccl_comm_create(ident, 1, 0, 0, C.byref(comm)))
+    pay = torch.arange(4096, dtype=torch.float32, device="cuda")
+    out = torch.zeros_like(pay)
+    n = (C.c_int64 * 1)(pay.numel())
+    P.capi.check(L.rt_gather_tiles_rccl(comm, 0, 1, C.c_void_p(pay.data_ptr()), n, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(pay, out)
+    L.rt_rccl_comm_destroy(comm)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracing-project_amd", "csrc", "rt_render")
+    obj, sav = os.path.join(SCENES, "redballs.obj"), os.path.join(SCENES, "cameras", "redballs.sav")
+    a, b = tmp_path / "forked", tmp_path / "plain"
+    a.mkdir(), b.mkdir()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(exe) + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    for args, d in ((["--gpus", "1"], a), ([], b)):
+        r = subprocess.run([exe, *args, obj, sav, "200", "120", "4", str(d)], env=env, capture_output=True, text=True,
+                           timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "rank 0 of 1" in r.stdout
+    for f in ("result.ppm", "result.bmp", "depth.bmp", "blurred.bmp"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
 @pytest.mark.parametrize("W,H", [(13, 13), (14, 13), (45, 21), (77, 20), (44, 33)])
 def test_dof_blur_ragged_sizes(P, oracle, W, H):
     """Frames from the smallest the blur accepts (one output pixel) through sizes that leave

@@ -143,6 +143,27 @@ def test_library_exports_every_declared_symbol(P):
         assert getattr(hl, name) is not None
 
 
+def test_rccl_gather_rejects_bad_arguments(P):
+    """Argument checks of the multi-GPU entry points come before any GPU or RCCL call."""
+    L = P.capi.lib()
+    n = (C.c_int64 * 2)(16, 16)
+    assert L.rt_gather_tiles_rccl(None, 0, 2, None, n, None, None) == -1
+    assert L.rt_gather_tiles_rccl(C.c_void_p(1), 2, 2, None, n, None, None) == -1
+    assert b"rank 2 of 2" in L.rt_last_error()
+    assert L.rt_gather_tiles_rccl(C.c_void_p(1), 0, 2, C.c_void_p(16), (C.c_int64 * 2)(16, -4), None, None) == -1
+    assert L.rt_gather_tiles_rccl(C.c_void_p(1), 1, 2, None, n, None, None) == -1          # payload missing
+    assert L.rt_gather_tiles_rccl(C.c_void_p(1), 0, 2, C.c_void_p(16), n, None, None) == -1  # no gather buffer on rank 0
+    assert L.rt_rccl_unique_id(None) == -1
+    comm = C.c_void_p()
+    ident = (C.c_ubyte * 128)()
+    assert L.rt_rccl_comm_create(ident, 0, 0, 0, C.byref(comm)) == -1
+    assert L.rt_rccl_comm_create(ident, 2, 2, 0, C.byref(comm)) == -1
+    L.rt_rccl_comm_destroy(None)
+    z = C.c_void_p()
+    assert L.rt_render_result_planes_shared(None, None, 0, 1, None, None, 0, None, C.byref(z), C.byref(z),
+                                            C.byref(z), None) == -1
+
+
 def test_struct_sizes_match_header(P):
     assert C.sizeof(P.capi.RtMaterial) == 64
     assert C.sizeof(P.capi.RtKdNode) == 40
