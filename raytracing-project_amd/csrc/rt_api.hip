@@ -501,6 +501,11 @@ struct RtScene {
     hipEvent_t  wf_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t  wf_fork = nullptr;
     size_t     wf_mem_bytes = 0;
+    // debug / ablation switches, read from the environment once, when the scene is created
+    struct {
+        bool megakernel = false, multilaunch = false, kd_stats = false;
+        int  pipes = 1, region = 0, stack_lds = 0, budget_mb = 0;
+    } cfg;
     // frame buffers of rt_render_result_planes: device planes + pinned host bytes, grown on demand
     void*       d_frame = nullptr;
     void*       h_frame = nullptr;
@@ -978,6 +983,14 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     RtScene* s = new RtScene();
     s->device = device;
     s->tree_depth = max_depth;
+    {
+        auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+        auto num = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; };
+        s->cfg.megakernel = on("RT_MEGAKERNEL"), s->cfg.multilaunch = on("RT_WF_MULTILAUNCH");
+        s->cfg.kd_stats = getenv("RT_KD_STATS") != nullptr;
+        s->cfg.pipes = std::max(1, num("RT_WF_PIPES")), s->cfg.region = num("RT_WF_REGION");
+        s->cfg.stack_lds = num("RT_WF_STACK_LDS"), s->cfg.budget_mb = num("RT_WF_BUDGET_MB");
+    }
     int rc;
     if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) ||
         (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
@@ -1249,8 +1262,7 @@ static int wf_prepare(RtScene* s)
     // LDS holds the first WF_STACK_LDS entries of every thread's traversal stack (fewer if the
     // tree is shallower); the rest of the tree's depth is backed by a buffer in HBM that is
     // touched only by the rare ray with that many far children pending.
-    const char* cap_env = getenv("RT_WF_STACK_LDS");
-    int         cap = cap_env ? atoi(cap_env) : WF_STACK_LDS;
+    int cap = s->cfg.stack_lds > 0 ? s->cfg.stack_lds : WF_STACK_LDS;
     cap = std::max(1, std::min(cap, (int)s->d.stack_entries));
     s->d.stk_cap = cap;
     s->wf_lds = (size_t)cap * WF_BLOCK * WF_STACK_ENTRY_BYTES;
@@ -1263,7 +1275,7 @@ static int wf_prepare(RtScene* s)
     const int g_any = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false>, WF_BLOCK, s->wf_lds));
     const int g_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
-    if (getenv("RT_KD_STATS"))
+    if (s->cfg.kd_stats)
         fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
                 (int)s->d.stack_entries, cap, s->wf_lds, per_cu);
     const size_t deep = (size_t)(s->d.stack_entries - cap);
@@ -1294,8 +1306,7 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
                               (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
                               (size_t)(2 + 2 * (1 + L)) * 4;
     size_t budget = WF_WORKSPACE_BUDGET;
-    if (const char* b_env = getenv("RT_WF_BUDGET_MB")) // tests: force a frame through several chunks
-        budget = (size_t)std::max(1, atoi(b_env)) << 20;
+    if (s->cfg.budget_mb > 0) budget = (size_t)s->cfg.budget_mb << 20; // tests: force a frame through several chunks
     long long g_max = (long long)(budget / n_pipes / per_region);
     g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
     g_max = std::max<long long>(g_max, 1);
@@ -1384,22 +1395,19 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     if (rc) return rc;
     const int L = std::max(P.n_lights, 1);
     // pipelines: enough chunks to overlap tails, but no chunk below ~64k pixel slots
-    const char* pipes_env = getenv("RT_WF_PIPES");
-    int         n_pipes = pipes_env ? atoi(pipes_env) : 1;
+    int n_pipes = s->cfg.pipes;
     n_pipes = std::max(1, std::min(n_pipes, WF_MAX_PIPES));
     n_pipes = (int)std::max<long long>(1, std::min<long long>(n_pipes, n_slots / 65536));
     // pixel slots per region: small regions balance the blocks of the single-launch pipeline
     // (a region is a block's unit of work), the multi-launch path is indifferent
-    const char* ml_env = getenv("RT_WF_MULTILAUNCH");
-    const bool  single = !(ml_env && ml_env[0] == '1');
-    const char* rg_env = getenv("RT_WF_REGION");
-    int         S = 512;
+    const bool single = !s->cfg.multilaunch;
+    int        S = 512;
     if (single) { // measured on a 4K MSAA4 frame: 128 slots for the whole frame (12.3 ms; 256: 12.6, 64: 13.5),
                   // 64 for an eighth of it (2.6 ms; 128: 3.0)
         const long long per_block = n_slots / (16LL * std::max(s->wf_grid_pipe, 1));
         S = per_block >= 512 ? 256 : (per_block >= 100 ? 128 : 64);
     }
-    if (rg_env) S = atoi(rg_env);
+    if (s->cfg.region > 0) S = s->cfg.region;
     S = std::max(64, std::min(4096, (S / 64) * 64));
     if (single) n_pipes = 1;
     WfPlan pl = wf_plan(s, P, (n_slots + n_pipes - 1) / n_pipes, n_pipes, S);
@@ -1529,8 +1537,7 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
     if (stats) memset(stats, 0, sizeof *stats);
     HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
-    const char* mk_env = getenv("RT_MEGAKERNEL");
-    const bool  wavefront = s->pushdown && s->d.n_nodes < 65536 && !(mk_env && mk_env[0] == '1');
+    const bool wavefront = s->pushdown && s->d.n_nodes < 65536 && !s->cfg.megakernel;
     if (n_slots > 0 && wavefront) {
         if ((rc = render_wavefront(s, P, n_slots, d_rgb, d_depth, d_tri, stream, stats != nullptr))) return rc;
     } else if (n_slots > 0) {

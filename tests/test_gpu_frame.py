@@ -378,6 +378,7 @@ def test_render_paths_agree(P, oracle, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        gs = hs.to_gpu(0)                                # the switches are read when a scene is created
         frames[name] = gs.render(corners, lights, P.capi.default_params(W, H, 4))
     for k in ("RT_WF_MULTILAUNCH", "RT_MEGAKERNEL", "RT_WF_REGION"):
         monkeypatch.delenv(k, raising=False)
