@@ -463,6 +463,48 @@ def test_rt_render_program(P, tmp_path):
     assert bad.returncode == 2 and "usage" in bad.stderr
 
 
+def test_png_textures_through_the_product_path(P, tmp_path):
+    """The scene's textures as PNG files next to the .obj (this repository carries them
+    pre-decoded, as .rtex): the loader must pick the PNG, decode it (png_decoder.cpp) and render
+    the frame the pre-decoded copy gives.  The PNGs are written here from the .rtex pixels."""
+    import shutil
+    import struct
+    import zlib
+
+    from test_host import _png_chunk
+    for name, W, H in (("final", 96, 54), ("lego", 80, 60)):
+        src = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
+        m, lights = P.host.read_camera_sav(os.path.join(SCENES, "cameras", name + ".sav"))
+        d = tmp_path / name
+        (d / "textures").mkdir(parents=True)
+        for f in os.listdir(SCENES):
+            if f.endswith((".obj", ".mtl")) and f.startswith(name):
+                shutil.copy(os.path.join(SCENES, f), d / f)
+        texs = src.arrays()["textures"]
+        assert texs
+        rtex = sorted(f for f in os.listdir(os.path.join(SCENES, "textures")) if f.endswith(".rtex"))
+        written = 0
+        for f in rtex:           # every shipped texture as a PNG; the loader opens the ones the .mtl names
+            raw = open(os.path.join(SCENES, "textures", f), "rb").read()
+            w, h, zl = struct.unpack("<III", raw[4:16])
+            px = np.frombuffer(zlib.decompress(raw[16:16 + zl]), np.uint8).reshape(h, w, 4)
+            lines = b"".join(b"\0" + px[y].tobytes() for y in range(h))
+            png = (b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0))
+                   + _png_chunk(b"IDAT", zlib.compress(lines)) + _png_chunk(b"IEND", b""))
+            (d / "textures" / f[:-5]).write_bytes(png)
+            written += 1
+        assert written == len(rtex)
+        via_png = P.host.HostScene(str(d / (name + ".obj")))
+        a, b = src.arrays(), via_png.arrays()
+        assert len(a["textures"]) == len(b["textures"]) > 0
+        for (pa, wa, ha), (pb, wb, hb) in zip(a["textures"], b["textures"]):
+            assert (wa, ha) == (wb, hb) and np.array_equal(pa, pb)
+        corners = P.host.camera_corners(m, W, H)
+        f1 = src.to_gpu(0).render(corners, lights, P.capi.default_params(W, H, 4))
+        f2 = via_png.to_gpu(0).render(corners, lights, P.capi.default_params(W, H, 4))
+        assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+
+
 def test_rccl_layer_with_one_rank(P, tmp_path):
     """What one GPU can exercise of the multi-GPU path in C: RCCL is found and bound, a
     communicator of one rank is made, the gather of one rank is the copy of its payload, and
