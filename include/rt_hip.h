@@ -107,7 +107,14 @@ typedef struct RtParams {
     int32_t tile_w, tile_h;
     int32_t rank, world;
     int32_t rank_span;
-    int32_t reserved;
+    /* settings.h:12-13.  shadowSamples <= 1: one shadow ray per light (the reference's default);
+     * n = 2..6: the soft shadows of raytracing.cpp:145-160, up to n^3 jittered shadow rays per
+     * light towards points around it (the float loops of the reference decide how many).  The
+     * reference jitters with rand(), whose order over its threads is not reproducible; here the
+     * three numbers of a sample come from a counter-based generator keyed by pixel, sample,
+     * position in the ray tree, light and sample ordinal, so frames are repeatable. */
+    int32_t shadowSamples;
+    float   shadowRadius;
 } RtParams;
 
 typedef struct RtStats {

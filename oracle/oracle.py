@@ -22,6 +22,8 @@ class Settings(C.Structure):
         ("depthPower", C.c_float),
         ("backgroundColor", C.c_float * 3),
         ("focusDepth", C.c_float),
+        ("shadowSamples", C.c_int),
+        ("shadowRadius", C.c_float),
     ]
 
 

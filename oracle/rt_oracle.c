@@ -93,6 +93,8 @@ void or_default_settings(or_settings *s)
     s->backgroundColor[1] = 0.5f;
     s->backgroundColor[2] = 1.0f;
     s->focusDepth = 0.0f;
+    s->shadowSamples = 1;          /* settings.h:13 */
+    s->shadowRadius = 0.9f;        /* settings.h:12 */
 }
 
 /* ------------------------------------------------------------------ */
@@ -921,8 +923,25 @@ static v3 get_texture(const or_scene *s, const or_material *m, const or_triangle
 /* shading recursion: raytracing.cpp:61-274                            */
 /* ------------------------------------------------------------------ */
 
+/* Soft shadows (raytracing.cpp:145-160) draw three rand() values per shadow sample.  rand()
+ * shared by up to 16 threads has no reproducible order, so its stream is NOT restated; the
+ * stand-in is a counter-based generator keyed by where the sample sits: id = 32 * (index of the
+ * camera ray: y * W + x for a frame, the ray's index for a batch) + sample number (0 = the
+ * pixel centre, 1.. = MSAA samples); path = the route from the camera ray to this hit, two bits
+ * per level (1 mirror, 2 transmitted, 3 reflected child); the light, the sample's ordinal in the
+ * x, y, z loops and the component.  It returns 0 .. 2^31 - 1, the range of rand() here. */
+uint32_t or_soft_rand(uint64_t id, uint32_t path, uint32_t light, uint32_t sample, uint32_t comp)
+{
+    uint64_t z = id * 0x9E3779B97F4A7C15ull +
+                 (((uint64_t)path << 24) | ((uint64_t)light << 16) | ((uint64_t)sample << 2) | comp);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 33);
+}
+
 static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, float *minT,
-                  int *firstTri, or_counters *c)
+                  int *firstTri, or_counters *c, uint64_t id, uint32_t path)
 {
     if (k > 5) return v3m(0, 0, 0);
     v3 resCol;
@@ -976,15 +995,37 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
             if (angle > 0.f) resCol = vadd(resCol, vscale(v3ld(mat->Ks), powf(angle, specularHighlight)));
             or_hit sh;
             v3 so = vadd(hitPoint, vscale(lightDir, 0.001f));
-            uint64_t t0 = c ? c->tri_tests : 0, s0 = c ? c->leaf_steps : 0;
-            or_check_hit(s, so.p, lpos.p, &sh, c);
-            if (c) c->rays_shadow++;
-            if (c && smFree == 1.f) {
-                c->moot_shadow_rays++;
-                c->moot_tri_tests += c->tri_tests - t0;
-                c->moot_leaf_steps += c->leaf_steps - s0;
+            const int shadowSamples = s->set.shadowSamples;
+            if (shadowSamples <= 1) {
+                uint64_t t0 = c ? c->tri_tests : 0, s0 = c ? c->leaf_steps : 0;
+                or_check_hit(s, so.p, lpos.p, &sh, c);
+                if (c) c->rays_shadow++;
+                if (c && smFree == 1.f) {
+                    c->moot_shadow_rays++;
+                    c->moot_tri_tests += c->tri_tests - t0;
+                    c->moot_leaf_steps += c->leaf_steps - s0;
+                }
+                if (sh.bHit) shadowMax = 1.f;
             }
-            if (sh.bHit) shadowMax = 1.f;
+            if (shadowSamples > 1) { /* raytracing.cpp:145-160 */
+                const float shadowRadius = s->set.shadowRadius;
+                float    delta = 2.f / (float)(shadowSamples - 1 + 0.000000000000000000001f);
+                uint32_t si = 0;
+                for (float x = -1.f; x <= 1.f; x += delta)
+                    for (float y = -1.f; y <= 1.f; y += delta)
+                        for (float z = -1.f; z <= 1.f; z += delta) {
+                            const double RM = 2147483647.0; /* RAND_MAX */
+                            float rx = delta / 2.f * (double)or_soft_rand(id, path, li, si, 0) / RM - delta / 4.f;
+                            float ry = delta / 2.f * (double)or_soft_rand(id, path, li, si, 1) / RM - delta / 4.f;
+                            float rz = delta / 2.f * (double)or_soft_rand(id, path, li, si, 2) / RM - delta / 4.f;
+                            ++si;
+                            v3 sd = vadd(lpos, v3m(x * shadowRadius + rx, y * shadowRadius + ry,
+                                                   z * shadowRadius + rz));
+                            or_check_hit(s, so.p, sd.p, &sh, c);
+                            if (c) c->rays_shadow++;
+                            if (sh.bHit) softShadow += 1.0f / shadowSamples / shadowSamples / shadowSamples;
+                        }
+            }
         }
         shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax; /* std::max(shadowMax, softShadow) */
         smFree = (smFree < softShadow) ? softShadow : smFree;
@@ -1003,7 +1044,7 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
         v3 newDest = vadd(hitPoint, reflectdir);
         float dummy;
         if (c) c->child_rays++;
-        v3 newCol = perform(s, newOrigin, newDest, newK, n2, &dummy, NULL, c);
+        v3 newCol = perform(s, newOrigin, newDest, newK, n2, &dummy, NULL, c, id, path * 4 + 1);
         return vadd(vscale(resCol, (float)0.5), vscale(newCol, (float)0.5));
     }
 
@@ -1024,14 +1065,14 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
             v3 newOriginT = vadd(hitPoint, vscale(tRay, 0.001f));
             v3 newDestT = vadd(hitPoint, tRay);
             if (c) c->child_rays++;
-            newColT = perform(s, newOriginT, newDestT, newK, n2, &dummy, NULL, c);
+            newColT = perform(s, newOriginT, newDestT, newK, n2, &dummy, NULL, c, id, path * 4 + 2);
             newColT = vadd(vscale(resCol, (float)0.1), vscale(newColT, (float)0.9));
         }
         v3 refRay = vsub(vInc, vscale(N, 2 * vdot(vInc, N)));
         v3 newOriginR = vadd(hitPoint, vscale(refRay, 0.001f));
         v3 newDestR = vadd(hitPoint, refRay);
         if (c) c->child_rays++;
-        newColR = perform(s, newOriginR, newDestR, newK, n2, &dummy, NULL, c);
+        newColR = perform(s, newOriginR, newDestR, newK, n2, &dummy, NULL, c, id, path * 4 + 3);
         newColR = vadd(vscale(resCol, (float)0.5), vscale(newColR, (float)0.5));
         float rf = sin2T;
         rf = (rf < 0 ? 0 : rf);
@@ -1044,7 +1085,7 @@ static v3 perform(const or_scene *s, v3 origin, v3 dest, int k, float prev_Ni, f
 void or_perform_ray_tracing(const or_scene *s, const float o[3], const float d[3], int k,
                             float prev_Ni, float *minT, float rgb[3], or_counters *c)
 {
-    v3 r = perform(s, v3ld(o), v3ld(d), k, prev_Ni, minT, NULL, c);
+    v3 r = perform(s, v3ld(o), v3ld(d), k, prev_Ni, minT, NULL, c, 0, 0);
     memcpy(rgb, r.p, 12);
 }
 
@@ -1116,7 +1157,7 @@ static void trace_one(job *j, int i, or_counters *c)
     rays_arg *A = (rays_arg *)j->arg;
     float     mt;
     int       ft = -1;
-    v3 r = perform(A->s, v3ld(A->o + 3 * i), v3ld(A->d + 3 * i), 0, 1.0f, &mt, &ft, c);
+    v3 r = perform(A->s, v3ld(A->o + 3 * i), v3ld(A->d + 3 * i), 0, 1.0f, &mt, &ft, c, (uint64_t)i * 32, 0);
     memcpy(A->rgb + 3 * i, r.p, 12);
     A->minT[i] = mt;
     if (A->tri) A->tri[i] = ft;
@@ -1286,12 +1327,12 @@ void or_pixel_ray(const float corners[24], int W, int H, double x, double y, flo
 }
 
 static v3 raytrace(const or_scene *s, const float corners[24], int W, int H, double x, double y,
-                   float *depth, int *tri, or_counters *c)
+                   float *depth, int *tri, or_counters *c, uint64_t id)
 {
     float o[3], d[3];
     or_pixel_ray(corners, W, H, x, y, o, d);
     if (c) c->camera_rays++;
-    return perform(s, v3ld(o), v3ld(d), 0, 1.0f, depth, tri, c);
+    return perform(s, v3ld(o), v3ld(d), 0, 1.0f, depth, tri, c, id, 0);
 }
 
 static void counters_add(or_counters *a, const or_counters *b);
@@ -1323,7 +1364,8 @@ static v3 raytrace_msaa(const or_scene *s, const float corners[24], int W, int H
     *depth = 0;
     or_counters cc;
     memset(&cc, 0, sizeof cc);
-    v3 rgb = raytrace(s, corners, W, H, x, y, &holder, primaryTri, &cc);
+    const uint64_t id0 = ((uint64_t)y * (uint64_t)W + (uint64_t)x) * 32;
+    v3 rgb = raytrace(s, corners, W, H, x, y, &holder, primaryTri, &cc, id0);
     if (c) counters_add(c, &cc);
     if (centre) counters_add(centre, &cc);
     depth_increase(depth, holder, &hitNumber);
@@ -1334,7 +1376,7 @@ static v3 raytrace_msaa(const or_scene *s, const float corners[24], int W, int H
         *depth = 0;
         hitNumber = 0;
         for (int i = 0; i < n; ++i) {
-            v3 r = raytrace(s, corners, W, H, x + off[i][0], y + off[i][1], &holder, NULL, c);
+            v3 r = raytrace(s, corners, W, H, x + off[i][0], y + off[i][1], &holder, NULL, c, id0 + 1 + i);
             rgb = i == 0 ? r : vadd(rgb, r);
             depth_increase(depth, holder, &hitNumber);
         }

@@ -39,6 +39,8 @@ typedef struct or_settings {
     float depthPower;         /* 2.5  */
     float backgroundColor[3]; /* 0.2 0.5 1.0 */
     float focusDepth;         /* raytracing.cpp:17, 0 unless key 'f' */
+    int   shadowSamples;      /* 1: hard shadows; n > 1: n^3 jittered shadow rays per light (settings.h:13) */
+    float shadowRadius;       /* 0.9 (settings.h:12) */
 } or_settings;
 
 /* work counters (one closest-hit or shadow query = one "ray") */
@@ -124,6 +126,9 @@ void or_check_hits(const or_scene *s, int n, const float *origins, const float *
 /* brute force over all triangles with the same triangle test (diagnostic) */
 void or_brute_hits(const or_scene *s, int n, const float *origins, const float *dests,
                    int32_t *tri, float *t);
+
+/* the counter-based stand-in for rand() in the soft-shadow loop (see rt_oracle.c) */
+uint32_t or_soft_rand(uint64_t id, uint32_t path, uint32_t light, uint32_t sample, uint32_t comp);
 
 /* ---- frame driver: main.cpp:43-56, 435-552 ---- */
 /* corners[8][3]: origin00 dest00 origin01 dest01 origin10 dest10 origin11 dest11 */

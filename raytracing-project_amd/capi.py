@@ -53,7 +53,8 @@ class RtParams(C.Structure):
                 ("ShadowFactor", C.c_float), ("depthPower", C.c_float),
                 ("backgroundColor", C.c_float * 3), ("focusDepth", C.c_float),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32),
-                ("world", C.c_int32), ("rank_span", C.c_int32), ("reserved", C.c_int32)]
+                ("world", C.c_int32), ("rank_span", C.c_int32), ("shadowSamples", C.c_int32),
+                ("shadowRadius", C.c_float)]
 
 
 class RtStats(C.Structure):

@@ -63,6 +63,7 @@ extern "C" void rt_default_params(RtParams* p, int32_t width, int32_t height)
     p->focusDepth = 0.0f;
     p->tile_w = p->tile_h = 0;
     p->rank = 0, p->world = 1;
+    p->shadowSamples = 1, p->shadowRadius = 0.9f; // settings.h:12-13
 }
 
 // ---------------------------------------------------------------------------
@@ -142,7 +143,8 @@ k_trace_rays(DScene S, DParams P, int k0, float prev_ni, long long n, const floa
         float    mt;
         int      ft;
         ncam = 1;
-        trace_sample(S, P, o, d, k0, prev_ni, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
+        trace_sample(S, P, o, d, k0, prev_ni, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch,
+                     (unsigned long long)i * 32);
         rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
         if (minT) minT[i] = mt;
         if (tri) tri[i] = ft;
@@ -172,7 +174,8 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
             f3    c;
             float mt;
             int   ft;
-            trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
+            trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch,
+                         (unsigned long long)p * 32);
             rgb[3 * p] = clamp01(c.x), rgb[3 * p + 1] = clamp01(c.y), rgb[3 * p + 2] = clamp01(c.z);
             depth[p] = mt; // FLT_MAX on a miss (main.cpp:442-443)
             if (tri) tri[p] = ft;
@@ -223,7 +226,8 @@ k_samples(DScene S, DParams P, long long n_slots, const unsigned char* __restric
         float mt;
         int   ft;
         ncam = 1;
-        trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch);
+        trace_sample(S, P, o, d, 0, 1.0f, s_stack + threadIdx.x, RT_BLOCK, c, mt, ft, nc, ns, nt, nn, nsh, nch,
+                     ((unsigned long long)y * P.W + x) * 32 + 1 + s);
         samples[slot * P.msaa + s] = make_float4(c.x, c.y, c.z, mt);
     }
     flush_counters(ctr, nc, ns, nt, nn, ncam, nsh, nch);
@@ -1088,6 +1092,19 @@ static int make_dparams(const RtParams* p, const float* camera, const float* lig
     memcpy(d->bg, p->backgroundColor, 12);
     if (camera) memcpy(d->cam, camera, sizeof d->cam);
     if (n_lights) memcpy(d->lights, lights, sizeof(float) * 3 * (size_t)n_lights);
+    if (p->shadowSamples < 0 || p->shadowSamples > 6)
+        return fail(RT_ERR_INVALID, "shadowSamples must be 0..6 (got %d)", p->shadowSamples);
+    if (p->shadowSamples > 1) { // raytracing.cpp:147-150, the loop in float as written there
+        const int      n = p->shadowSamples;
+        volatile float delta = 2.f / (float)(n - 1 + 0.000000000000000000001f);
+        int            cnt = 0;
+        for (volatile float x = -1.f; x <= 1.f; x += delta)
+            if (cnt < 8) d->soft_x[cnt++] = x;
+        d->soft_n = cnt;
+        d->soft_half = delta / 2.f, d->soft_quarter = delta / 4.f;
+        d->soft_w = 1.0f / n / n / n;
+        d->soft_radius = p->shadowRadius;
+    }
     return RT_OK;
 }
 
@@ -1273,7 +1290,7 @@ static int wf_prepare(RtScene* s)
     const int g_trace = std::max(1, per_cu) * prop.multiProcessorCount;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace<true>, WF_BLOCK, s->wf_lds));
     const int g_any = std::max(1, per_cu) * prop.multiProcessorCount;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false>, WF_BLOCK, s->wf_lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false, false>, WF_BLOCK, s->wf_lds));
     const int g_pipe = std::max(1, per_cu) * prop.multiProcessorCount;
     if (s->cfg.kd_stats)
         fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
@@ -1293,6 +1310,7 @@ struct WfPlan {
     int       S;           // pixel slots per region
     int       G, R;        // regions per chunk, ray slots per region
     int       n_samples;   // samples per chunk
+    int       ns;          // shadow rays per hit and light
 };
 
 static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes, int S)
@@ -1302,7 +1320,8 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
     const int       growth = s->refractive ? 16 : 1;
     const int       L = std::max(P.n_lights, 1);
     const long long R = (long long)S * P.msaa * growth;
-    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8 + 16) + 4 + (size_t)L * 17) +
+    const int       ns = P.soft_n > 0 ? P.soft_n * P.soft_n * P.soft_n : 1;
+    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8 + 16) + 4 + (size_t)L * (1 + 16 * (size_t)ns * (ns > 1 ? 2 : 1))) +
                               (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
                               (size_t)(2 + 2 * (1 + L)) * 4;
     size_t budget = WF_WORKSPACE_BUDGET;
@@ -1315,6 +1334,7 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
     pl.G = (int)std::min(g_need, g_max);
     pl.R = (int)R;
     pl.S = S;
+    pl.ns = ns;
     pl.chunk_slots = (long long)pl.G * S;
     pl.n_samples = (int)(pl.chunk_slots * P.msaa);
     return pl;
@@ -1335,7 +1355,7 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
     for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 8), take(G * 4); // 0..7
     take(cap * 16 * 2);                        // 8 hits, one set per queue
     take(cap * 4);                             // 9 wlocal
-    take(cap * 16 * (size_t)L);                // 10 sh_org
+    take(cap * 16 * (size_t)L * pl.ns);        // 10 sh_org
     take(G * 4 * (size_t)L);                   // 11 sh_cnt
     take(cap * (size_t)L);                     // 12 occl
     take(((G + 1) + (G * (size_t)L + 1)) * 4); // 13 prefix
@@ -1344,6 +1364,7 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
     take(ns * 4);                              // 16 s_tri
     take(sizeof(WfCounters));                  // 17
     take((size_t)pl.chunk_slots);              // 18 centre flags
+    take(pl.ns > 1 ? cap * 16 * (size_t)L * pl.ns : 0); // 19 sh_dst
     return need;
 }
 
@@ -1368,6 +1389,8 @@ static void wf_carve(unsigned char* m, const WfPlan& pl, WfBuffers* B, unsigned 
     B->s_tri = (int*)(m + off[16]);
     B->ctr = (WfCounters*)(m + off[17]);
     *centre_flags = m + off[18];
+    B->sh_dst = (float4*)(m + off[19]);
+    B->ns = pl.ns;
     B->cap = pl.G * pl.R;
     B->G = pl.G, B->R = pl.R, B->S = pl.S;
     B->n_samples = pl.n_samples;
@@ -1401,6 +1424,8 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     // pixel slots per region: small regions balance the blocks of the single-launch pipeline
     // (a region is a block's unit of work), the multi-launch path is indifferent
     const bool single = !s->cfg.multilaunch;
+    if (!single && P.soft_n > 0)
+        return fail(RT_ERR_UNSUPPORTED, "soft shadows are not available with RT_WF_MULTILAUNCH=1");
     int        S = 512;
     if (single) { // measured on a 4K MSAA4 frame: 128 slots for the whole frame (12.3 ms; 256: 12.6, 64: 13.5),
                   // 64 for an eighth of it (2.6 ms; 128: 3.0)
@@ -1448,12 +1473,10 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         if (single) {
             hipStream_t st = s->wf_stream[0];
             HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
-            if (count)
-                hipLaunchKernelGGL(k_wf_pipeline<true>, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d,
-                                   P, C[0], slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
-            else
-                hipLaunchKernelGGL(k_wf_pipeline<false>, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d,
-                                   P, C[0], slot0[0], n[0], d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
+            auto kern = P.soft_n > 0 ? (count ? k_wf_pipeline<true, true> : k_wf_pipeline<false, true>)
+                                     : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
+            hipLaunchKernelGGL(kern, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d, P, C[0], slot0[0], n[0],
+                               d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
             HIP_TRY(hipGetLastError());
             continue;
         }

@@ -69,7 +69,42 @@ struct DParams {
     int32_t tiles_x, tiles_y, n_my_tiles, span; // span: consecutive shares this call covers, from `rank`
     float   cam[24];
     float   lights[3 * RT_MAX_LIGHTS_DEV];
+    // soft shadows (raytracing.cpp:145-160): soft_n = values the reference's float loop
+    // `for (x = -1; x <= 1; x += delta)` takes (0 = hard shadows), soft_x those values,
+    // soft_w = 1.0f / n / n / n, the jitter terms delta / 2 and delta / 4
+    int32_t soft_n, pad2;
+    float   soft_half, soft_quarter, soft_w, soft_radius;
+    float   soft_x[8];
 };
+
+// The counter-based stand-in for the rand() calls of raytracing.cpp:151-153: 0 .. 2^31 - 1 from
+// (camera ray id, route through the ray tree, light, sample ordinal, component).
+__device__ __forceinline__ unsigned soft_rand(unsigned long long id, unsigned path, unsigned light, unsigned sample,
+                                              unsigned comp)
+{
+    unsigned long long z = id * 0x9E3779B97F4A7C15ull +
+                           (((unsigned long long)path << 24) | ((unsigned long long)light << 16) |
+                            ((unsigned long long)sample << 2) | comp);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 33);
+}
+
+// Destination of soft-shadow sample `si` of light `li` (raytracing.cpp:148-154)
+__device__ __forceinline__ void soft_dest(const float* lights, const float* soft_x, int soft_n, float half,
+                                          float quarter, float radius, int li, int si, unsigned long long id,
+                                          unsigned path, float& dx, float& dy, float& dz)
+{
+    const int    iz = si % soft_n, iy = (si / soft_n) % soft_n, ix = si / (soft_n * soft_n);
+    const double RM = 2147483647.0;
+    const float  rx = (float)((double)half * (double)soft_rand(id, path, li, si, 0) / RM - (double)quarter);
+    const float  ry = (float)((double)half * (double)soft_rand(id, path, li, si, 1) / RM - (double)quarter);
+    const float  rz = (float)((double)half * (double)soft_rand(id, path, li, si, 2) / RM - (double)quarter);
+    dx = lights[3 * li] + (soft_x[ix] * radius + rx);
+    dy = lights[3 * li + 1] + (soft_x[iy] * radius + ry);
+    dz = lights[3 * li + 2] + (soft_x[iz] * radius + rz);
+}
 
 struct DCounters {
     unsigned long long rays_closest, rays_shadow, tri_tests, node_visits, camera_rays;
@@ -319,6 +354,7 @@ struct PendingRay {
     float w;  // path weight of this ray's colour in the camera sample
     float ni; // prev_Ni handed to performRayTracing
     int   k;
+    unsigned path; // route from the camera ray, two bits per level (1 mirror, 2 transmitted, 3 reflected)
 };
 
 // One camera sample: performRayTracing(origin, dest, k0, prev_ni, minT) of
@@ -328,11 +364,11 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                                              int k0, float prev_ni, uint2* stk, int stride, f3& rgb, float& minT_out,
                                              int& tri_out, unsigned& n_closest, unsigned& n_shadow,
                                              unsigned& n_tests, unsigned& n_nodes, unsigned& n_shaded,
-                                             unsigned& n_child)
+                                             unsigned& n_child, unsigned long long id = 0)
 {
     PendingRay pend[RT_MAX_PENDING];
     int        np = 1;
-    pend[0].o = origin, pend[0].d = dest, pend[0].w = 1.0f, pend[0].ni = prev_ni, pend[0].k = k0;
+    pend[0].o = origin, pend[0].d = dest, pend[0].w = 1.0f, pend[0].ni = prev_ni, pend[0].k = k0, pend[0].path = 0;
     f3   acc = mk3(0.0f, 0.0f, 0.0f);
     bool first = true;
     const float shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
@@ -385,17 +421,29 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                 angle -= 0.2f;
                 shadowMax = 3.33f * (0.3f - angle);
             }
+            float softShadow = 0.0f;
             if (angle > 0.0f) {
                 f3 halfway = lightDir + viewDir;
                 normalize3(halfway);
                 angle = dot3(N, halfway);
                 if (angle > 0.0f) res = res + Ks * powf(angle, Ns);
-                HitRec sh;
-                ++n_shadow;
-                if (kd_trace<true>(S, hp + lightDir * 0.001f, lpos, stk, stride, sh, n_tests, n_nodes))
-                    shadowMax = 1.0f;
+                HitRec   sh;
+                const f3 so = hp + lightDir * 0.001f;
+                if (P.soft_n == 0) {
+                    ++n_shadow;
+                    if (kd_trace<true>(S, so, lpos, stk, stride, sh, n_tests, n_nodes)) shadowMax = 1.0f;
+                } else { // raytracing.cpp:145-160
+                    const int ns = P.soft_n * P.soft_n * P.soft_n;
+                    for (int si = 0; si < ns; ++si) {
+                        f3 sd;
+                        soft_dest(P.lights, P.soft_x, P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si,
+                                  id, r.path, sd.x, sd.y, sd.z);
+                        ++n_shadow;
+                        if (kd_trace<true>(S, so, sd, stk, stride, sh, n_tests, n_nodes)) softShadow += P.soft_w;
+                    }
+                }
             }
-            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow = 0)
+            shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax; // std::max(shadowMax, softShadow)
             const float sm = shadowMax * shadowPart;
             res = res - mk3(sm, sm, sm);
         }
@@ -411,7 +459,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
             acc = acc + res * (0.5f * r.w);
             ++n_child;
             PendingRay& c = pend[np++];
-            c.o = hp + refl * 0.001f, c.d = hp + refl, c.w = 0.5f * r.w, c.ni = n2, c.k = newK;
+            c.o = hp + refl * 0.001f, c.d = hp + refl, c.w = 0.5f * r.w, c.ni = n2, c.k = newK, c.path = r.path * 4 + 1;
             continue;
         }
         if (Ni > 1.0f) { // raytracing.cpp:206-271
@@ -435,7 +483,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                 if (wT != 0.0f) {
                     ++n_child;
                     PendingRay& c = pend[np++];
-                    c.o = hp + tRay * 0.001f, c.d = hp + tRay, c.w = wT, c.ni = n2, c.k = newK;
+                    c.o = hp + tRay * 0.001f, c.d = hp + tRay, c.w = wT, c.ni = n2, c.k = newK, c.path = r.path * 4 + 2;
                 }
             }
             const float wR = 0.5f * rf * r.w;
@@ -443,7 +491,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                 const f3    refRay = I - N * (2.0f * dot3(I, N));
                 ++n_child;
                 PendingRay& c = pend[np++];
-                c.o = hp + refRay * 0.001f, c.d = hp + refRay, c.w = wR, c.ni = n2, c.k = newK;
+                c.o = hp + refRay * 0.001f, c.d = hp + refRay, c.w = wR, c.ni = n2, c.k = newK, c.path = r.path * 4 + 3;
             }
             acc = acc + res * (wLocal * r.w);
             continue;

@@ -80,9 +80,10 @@ struct WfRays {
 struct WfBuffers {
     WfRays         rays[2];   // ping-pong between levels
     float*         wlocal;    // per ray slot: weight of the hit's own colour (0 for a miss)
-    float4*        sh_org;    // [light][cap]: shadow ray origin xyz, bits(ray slot)
+    float4*        sh_org;    // [light][cap * ns]: shadow ray origin xyz, bits(ray slot)
+    float4*        sh_dst;    // [light][cap * ns]: soft shadows only, the sample's destination
     int*           sh_cnt;    // [light][G]
-    unsigned char* occl;      // [light][cap]: 1 = occluded, indexed by ray slot
+    unsigned char* occl;      // [light][cap]: 1 = occluded (soft shadows: occluded samples), indexed by ray slot
     int*           prefix;    // [G + 1] for the ray queue, then [lights * G + 1] for the shadow queues
     long long*     acc;       // [3][n_samples] fixed-point colour sums
     float*         s_minT;    // per sample: t of the camera ray's hit (FLT_MAX = miss)
@@ -92,6 +93,7 @@ struct WfBuffers {
     int            G, R;      // regions, ray slots per region
     int            S;         // pixel slots per region
     int            n_samples; // samples of a chunk (upper bound)
+    int            ns;        // shadow rays per hit and light: 1, or soft_n^3 with soft shadows
 };
 
 // ---------------------------------------------------------------------------
@@ -428,9 +430,10 @@ __device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lig
 // ---------------------------------------------------------------------------
 // shade: one block per region, one thread per ray of level `level`
 // ---------------------------------------------------------------------------
+template <bool SOFT = false>
 __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& P, const WfBuffers& B,
                                                 const WfRays in, const WfRays out, int r, WfShared* sh,
-                                                unsigned& n_shaded, unsigned& n_child)
+                                                unsigned& n_shaded, unsigned& n_child, long long slot0 = 0)
 {
     int&         s_child = sh->child;
     int*         s_sh = sh->sh;
@@ -473,20 +476,39 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                 // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
                 // shadowMax is its value with every query so far answered "free"; if that is 1
                 // already - set by a grazing angle at this light, or carried from an earlier one -
-                // the answer cannot change the colour and the query is not traced.
-                if (shadowMax == 1.0f) cast = false;
+                // the answer cannot change the colour and the query is not traced.  (Soft shadows
+                // take the maximum with a sum that rounding may carry past 1: all of them are traced.)
+                if (!SOFT && shadowMax == 1.0f) cast = false;
                 shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax;
             }
-            const int pos = wf_append(&s_sh[li], cast);
+            const int pos = wf_append(&s_sh[li], cast, SOFT ? B.ns : 1);
             if (cast) {
                 const f3 so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
-                B.sh_org[(size_t)li * B.cap + base + pos] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+                if (!SOFT) {
+                    B.sh_org[(size_t)li * B.cap + base + pos] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+                } else { // raytracing.cpp:145-160: ns rays towards jittered points around the light
+                    const int slot = P.msaa == 1 ? (int)meta.x : (int)(meta.x / (unsigned)P.msaa);
+                    const int sn = P.msaa == 1 ? 0 : (int)(meta.x % (unsigned)P.msaa) + 1;
+                    int       px = 0, py = 0;
+                    slot_to_pixel(P, slot0 + slot, px, py);
+                    const unsigned long long id = ((unsigned long long)py * P.W + px) * 32 + sn;
+                    const size_t             q0 = ((size_t)li * B.cap + base) * B.ns + pos;
+                    B.occl[(size_t)li * B.cap + i] = 0;
+                    for (int si = 0; si < B.ns; ++si) {
+                        float4 dd = make_float4(0, 0, 0, 0);
+                        soft_dest(P.lights, P.soft_x, P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si, id,
+                                  (meta.y >> 16) & 0xffu, dd.x, dd.y, dd.z);
+                        B.sh_org[q0 + si] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+                        B.sh_dst[q0 + si] = dd;
+                    }
+                }
             }
         }
         // ---- children, raytracing.cpp:166-271 ----
-        int   nchild = 0;
-        f3    c_o[2], c_d[2];
-        float c_w[2];
+        int      nchild = 0;
+        f3       c_o[2], c_d[2];
+        float    c_w[2];
+        unsigned c_kind[2] = {0, 0}; // 1 mirror, 2 transmitted, 3 reflected (the soft-shadow generator's key)
         float n2 = 1.0f;
         if (is_hit) {
             wl = w;
@@ -497,7 +519,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                 if (s.illum == 3) {
                     const f3 refl = s.dir - s.N * (2.0f * dot3(s.N, s.dir));
                     wl = 0.5f * w;
-                    c_o[0] = s.hp + refl * 0.001f, c_d[0] = s.hp + refl, c_w[0] = 0.5f * w;
+                    c_o[0] = s.hp + refl * 0.001f, c_d[0] = s.hp + refl, c_w[0] = 0.5f * w, c_kind[0] = 1;
                     nchild = 1;
                 } else if (s.Ni > 1.0f) {
                     f3 I = s.dir;
@@ -517,6 +539,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                         const float wT = 0.9f * (1.0f - rf) * w;
                         if (wT != 0.0f) {
                             c_o[nchild] = s.hp + tRay * 0.001f, c_d[nchild] = s.hp + tRay, c_w[nchild] = wT;
+                            c_kind[nchild] = 2;
                             ++nchild;
                         }
                     }
@@ -524,6 +547,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                     if (wR != 0.0f) {
                         const f3 refRay = I - s.N * (2.0f * dot3(I, s.N));
                         c_o[nchild] = s.hp + refRay * 0.001f, c_d[nchild] = s.hp + refRay, c_w[nchild] = wR;
+                        c_kind[nchild] = 3;
                         ++nchild;
                     }
                     wl = wLocal * w;
@@ -540,7 +564,8 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                 const size_t p = base + pos;
                 out.o_w[p] = make_float4(c_o[c].x, c_o[c].y, c_o[c].z, c_w[c]);
                 out.d_ni[p] = make_float4(c_d[c].x, c_d[c].y, c_d[c].z, n2);
-                out.meta[p] = make_uint2(meta.x, (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8));
+                const unsigned path = (((meta.y >> 16) & 0x3fu) << 2) | c_kind[c];
+                out.meta[p] = make_uint2(meta.x, (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8) | (path << 16));
             }
         }
     }
@@ -565,6 +590,7 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level, DCounters* ctr)
 // ---------------------------------------------------------------------------
 // resolve: the light loop of raytracing.cpp:110-164 with the shadow queries answered
 // ---------------------------------------------------------------------------
+template <bool SOFT = false>
 __device__ __forceinline__ void wf_resolve_region(const DScene& S, const DParams& P, const WfBuffers& B,
                                                   const WfRays in, int r)
 {
@@ -601,9 +627,16 @@ __device__ __forceinline__ void wf_resolve_region(const DScene& S, const DParams
                 normalize3(halfway);
                 angle = dot3(s.N, halfway);
                 if (angle > 0.0f) res = res + s.Ks * powf(angle, s.Ns);
-                if (B.occl[(size_t)li * B.cap + i]) shadowMax = 1.0f;
+                const int occluded = B.occl[(size_t)li * B.cap + i];
+                if (!SOFT) {
+                    if (occluded) shadowMax = 1.0f;
+                } else { // raytracing.cpp:155-157: one float addition per occluded sample
+                    float softShadow = 0.0f;
+                    for (int c = 0; c < occluded; ++c) softShadow += P.soft_w;
+                    shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax;
+                }
             }
-            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow = 0)
+            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow) with softShadow >= 0
             const float sm = shadowMax * shadowPart;
             res = res - mk3(sm, sm, sm);
         }
@@ -821,7 +854,7 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
 // region's chain of dependent stages is one trace per level instead of two.  The index
 // space is [closest rays][light 0][light 1]..., each segment padded to whole waves so a
 // wave runs one kind of walk; the closest-hit rays (the longer walks) start first.
-template <bool COUNT>
+template <bool COUNT, bool SOFT = false>
 __device__ __forceinline__ void wf_trace_merged(const DScene& S, const DParams& P, const WfBuffers& B,
                                                 const WfRays next, int n_next, int r, const WfStack& stk,
                                                 unsigned& n_tests, unsigned& n_nodes, unsigned& n_closest,
@@ -849,13 +882,23 @@ __device__ __forceinline__ void wf_trace_merged(const DScene& S, const DParams& 
                 n_li = B.sh_cnt[(size_t)li * B.G + r];
             }
             if (j >= n_li) continue;
-            const float4 ow = B.sh_org[(size_t)li * B.cap + base + j];
+            const size_t qi = SOFT ? ((size_t)li * B.cap + base) * B.ns + j : (size_t)li * B.cap + base + j;
+            const float4 ow = B.sh_org[qi];
             const f3     o = mk3(ow.x, ow.y, ow.z);
-            const f3     l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
-            HitRec       h;
+            f3           l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
+            if (SOFT) {
+                const float4 dd = B.sh_dst[qi];
+                l = mk3(dd.x, dd.y, dd.z);
+            }
+            HitRec h;
             ++n_shadow;
             const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, n_tests, n_nodes);
-            B.occl[(size_t)li * B.cap + __float_as_int(ow.w)] = got ? 1 : 0;
+            if (!SOFT) {
+                B.occl[(size_t)li * B.cap + __float_as_int(ow.w)] = got ? 1 : 0;
+            } else if (got) { // count in the hit's byte (at most 216 samples): add into its 32-bit word
+                const size_t b = (size_t)li * B.cap + (size_t)__float_as_int(ow.w);
+                atomicAdd((unsigned*)(B.occl + (b & ~(size_t)3)), 1u << (8 * (unsigned)(b & 3)));
+            }
         }
     }
 }
@@ -874,7 +917,7 @@ __device__ unsigned long long g_timeline[WF_TL_REGIONS * 16];
 #else
 #define WF_TL(slot) do { } while (0)
 #endif
-template <bool COUNT>
+template <bool COUNT, bool SOFT>
 __global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
 k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* rgb, float* depth, int* tri,
               unsigned char* centre_hit, DCounters* ctr)
@@ -917,18 +960,18 @@ k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* r
         WF_TL(2);
         // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
         if (B.rays[q].cnt[r] > 0) {
-            wf_shade_region(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh, n_shaded, n_child);
+            wf_shade_region<SOFT>(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh, n_shaded, n_child, slot0);
             __syncthreads();
             for (int level = 0; level < 5; ++level, q ^= 1) {
                 const WfRays in = B.rays[q], out = B.rays[q ^ 1];
                 const int    n_out = out.cnt[r];
-                wf_trace_merged<COUNT>(S, P, B, out, n_out, r, stk, n_tests, n_nodes, n_closest, n_shadow);
+                wf_trace_merged<COUNT, SOFT>(S, P, B, out, n_out, r, stk, n_tests, n_nodes, n_closest, n_shadow);
                 __syncthreads();
                 WF_TL(3 + 2 * level);
-                wf_resolve_region(S, P, B, in, r);
+                wf_resolve_region<SOFT>(S, P, B, in, r);
                 if (n_out == 0) break;
                 __syncthreads(); // resolve still reads the queue the next shade writes its children to
-                wf_shade_region(S, P, B, out, in, r, &sh, n_shaded, n_child);
+                wf_shade_region<SOFT>(S, P, B, out, in, r, &sh, n_shaded, n_child, slot0);
                 __syncthreads();
                 WF_TL(4 + 2 * level);
             }

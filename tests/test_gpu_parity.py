@@ -200,3 +200,52 @@ def test_random_scenes_match_oracle(oracle, seed):
     diff = np.abs(oracle.to_bytes(grgb).astype(int) - oracle.to_bytes(frgb).astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} of {diff.size} pixels off by > 1 LSB"
     assert st.rays_closest > W * H
+
+
+@pytest.mark.parametrize("name,n,msaa,W,H", [("redballs", 2, 1, 120, 68), ("refractionballs", 2, 4, 96, 54),
+                                             ("final", 3, 4, 64, 36), ("ball", 4, 1, 64, 64)])
+def test_soft_shadows_match_oracle(oracle, name, n, msaa, W, H):
+    """shadowSamples = n > 1 (raytracing.cpp:145-160): up to n^3 jittered shadow rays per light,
+    the jitter from the counter-based generator both sides share (the reference's rand() stream
+    is not reproduced).  Frames through the wavefront pipeline and batched rays through
+    rt_trace_rays."""
+    capi = pkg().capi
+    s = oracle.Scene.load(os.path.join(SCENES, name + ".obj"))
+    m, lights = oracle.read_camera_sav(os.path.join(SCENES, "cameras", name + ".sav"))
+    s.set_lights(lights)
+    s.settings.MSAA = msaa
+    s.settings.shadowSamples = n
+    gs = gpu_scene_from_oracle(s)
+    corners = oracle.camera_corners(m, W, H)
+    p = capi.default_params(W, H, msaa)
+    p.shadowSamples = n
+    rgb, depth, tri, st = gs.render(corners, lights, p)
+    c = oracle.Counters()
+    orgb, odepth, otri = s.render(corners, W, H, threads=8, counters=c)
+    assert (tri == otri).mean() >= 0.9999 and np.array_equal(depth == depth, odepth == odepth)
+    d = np.abs(oracle.to_bytes(rgb).astype(int) - oracle.to_bytes(orgb).astype(int)).max(axis=2)
+    assert (d <= 1).mean() >= 0.999, (d > 1).sum()
+    x, delta, loops = np.float32(-1), np.float32(2) / np.float32(n - 1), 0
+    while x <= np.float32(1):                                # the reference's loop, in float
+        x, loops = np.float32(x + delta), loops + 1
+    assert st.rays_shadow % loops ** 3 == 0 and st.rays_shadow > 0
+    if msaa == 1:                                            # no query is elided with soft shadows
+        assert abs(st.rays_shadow - c.rays_shadow) <= 1e-3 * c.rays_shadow
+    else:                                                    # (the discarded pixel-centre subtrees are not traced)
+        assert st.rays_shadow <= c.rays_shadow
+    hard = gs.render(corners, lights, capi.default_params(W, H, msaa))
+    assert not np.array_equal(hard[0], rgb)                    # penumbrae differ from hard shadows
+    # the same through the batched entry point: ray i is keyed by its index
+    g = load_golden(name)
+    o, dd = g["origins"][:2000], g["dests"][:2000]
+    p1 = capi.default_params(64, 64)
+    p1.shadowSamples = n
+    grgb, gmt, gtri, _ = gs.trace_rays(o, dd, lights, params=p1)
+    s.settings.MSAA = 1
+    rrgb, rmt, rtri = s.trace_rays(o, dd, threads=8)
+    assert (gtri == rtri).mean() >= 0.9999
+    same = gtri == rtri
+    assert np.abs(grgb[same] - rrgb[same]).max() < 2e-5
+    p1.shadowSamples = 7
+    with pytest.raises(capi.RtError, match="shadowSamples"):
+        gs.trace_rays(o[:1], dd[:1], lights, params=p1)

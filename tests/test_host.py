@@ -167,7 +167,7 @@ def test_rccl_gather_rejects_bad_arguments(P):
 def test_struct_sizes_match_header(P):
     assert C.sizeof(P.capi.RtMaterial) == 64
     assert C.sizeof(P.capi.RtKdNode) == 40
-    assert C.sizeof(P.capi.RtParams) == 68
+    assert C.sizeof(P.capi.RtParams) == 72
     assert C.sizeof(P.capi.RtStats) == 64
 
 

@@ -203,3 +203,27 @@ def test_texture_wrap_and_padding(oracle):
     assert len(t) == 1 and t[0][1:] == (100, 100)
     px = t[0][0].reshape(102, 100, 4)
     assert (px[100:] == 0).all() and px[:100].any()
+
+
+def test_soft_shadow_generator_and_loop(oracle):
+    """The counter-based stand-in for rand() is a pure function of its key, and soft shadows
+    (settings.h:13 shadowSamples > 1) shade penumbrae between lit and fully shadowed."""
+    L = oracle.lib()
+    import ctypes as C
+    L.or_soft_rand.restype = C.c_uint32
+    L.or_soft_rand.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    a = [L.or_soft_rand(12345, 6, 1, k, 2) for k in range(64)]
+    assert a == [L.or_soft_rand(12345, 6, 1, k, 2) for k in range(64)] and len(set(a)) == 64
+    assert max(a) < 2 ** 31 and L.or_soft_rand(12345, 6, 1, 0, 2) != L.or_soft_rand(12346, 6, 1, 0, 2)
+    s = oracle.Scene.load(os.path.join(SCENES, "redballs.obj"))
+    m, lights = oracle.read_camera_sav(os.path.join(SCENES, "cameras", "redballs.sav"))
+    s.set_lights(lights)
+    W, H = 64, 36
+    corners = oracle.camera_corners(m, W, H)
+    c1, c2 = oracle.Counters(), oracle.Counters()
+    hard, _, _ = s.render(corners, W, H, threads=4, counters=c1)
+    s.settings.shadowSamples = 2
+    soft, _, _ = s.render(corners, W, H, threads=4, counters=c2)
+    again, _, _ = s.render(corners, W, H, threads=2)
+    assert np.array_equal(soft, again)                       # repeatable whatever the thread count
+    assert c2.rays_shadow == 8 * c1.rays_shadow and not np.array_equal(hard, soft)
