@@ -152,8 +152,10 @@ def config_record(pkg, name, w, h, msaa, fc, dev_index, frames=5):
     ms = kt.frame_ms / max(kt.frames, 1)
     rays = st.rays_closest + st.rays_shadow
     key = f"{name}_{w}x{h}_msaa{msaa}"
+    info = gs.info()
     rec = {"ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1), "rays_per_frame": int(rays),
-           "lights": len(lights), "launches_timed": kt.frames}
+           "lights": len(lights), "launches_timed": kt.frames,
+           "scene_create_ms": round(info["create_ms"], 2), "tree_steps_ms": round(info["tree_ms"], 2)}
     if fc.get(key):
         f_needed = fc[key].get("flops_needed", fc[key]["flops_frame"])
         rec["frac"] = round(f_needed / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
@@ -586,6 +588,10 @@ def main():
         if n_flight == 1:
             out["kernel_ms"]["dof_and_gather"] = round(ms - kt.frame_ms / max(kt.frames, 1), 3)
         out["config"]["frames_in_flight"] = n_flight
+        info = gs.info()
+        out["scene_create_ms"] = {"rt_scene_create": round(info["create_ms"], 2),
+                                  "tree_hand_down_and_refine": round(info["tree_ms"], 2),
+                                  "on_gpu": bool(info["tree_on_gpu"]), "device_nodes": info["n_nodes"]}
         if world == 1 and not args.no_extras:
             fc_all = json.load(open(fc_path)) if os.path.exists(fc_path) else {}
             out["configs"] = {f"{n_}_{w_}x{h_}_msaa{m_}": config_record(pkg, n_, w_, h_, m_, fc_all, local)

@@ -136,6 +136,11 @@ typedef struct RtStats {
 typedef struct RtSceneInfo {
     int32_t  n_nodes, n_triangles, tree_depth, n_slots;
     uint64_t device_bytes;
+    uint64_t tree_hash;  /* FNV-1a over the device tree's nodes and slots: equal trees, equal hash */
+    float    create_ms;  /* wall time of rt_scene_create */
+    float    tree_ms;    /* of which: handing triangles down + splitting leaves */
+    int32_t  tree_on_gpu; /* 1: those two steps ran on the device, 0: on the host (RT_KD_GPU=0) */
+    int32_t  reserved;
 } RtSceneInfo;
 
 /* Per-kernel device time of the render calls since timing was switched on or

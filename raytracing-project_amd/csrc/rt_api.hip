@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,7 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_device.h"
+#include "rt_kdrefine.h"
 
 #pragma clang fp contract(off)
 
@@ -486,6 +488,9 @@ struct RtScene {
     void*   d_knodes = nullptr;
     int     tree_depth = 0;
     size_t  bytes = 0;
+    uint64_t tree_hash = 0;            // FNV-1a over the compact nodes and the triangle of every slot
+    float    create_ms = 0, tree_ms = 0; // rt_scene_create in all / its two tree transformations
+    int      tree_on_gpu = 0;
     // per-call workspace, grown on demand
     DCounters*     d_ctr = nullptr;
     unsigned char* d_flags = nullptr;
@@ -586,10 +591,183 @@ extern "C" void rt_scene_destroy(RtScene* s)
     delete s;
 }
 
+// device memory that lives for one call
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    int alloc(size_t bytes)
+    {
+        release();
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return RT_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// the tree transformations of rt_scene_create on the device (rt_kdrefine.h)
+// ---------------------------------------------------------------------------
+// Level by level: the device filters and splits the triangle lists (one block per node of the
+// level), the host keeps the node arrays and numbers new nodes in the order the host loops would.
+// Returns 0 when the arrays now hold the transformed tree, 1 when the triangle pool overflowed
+// (nothing changed, the caller runs the host loops), < 0 on a HIP error.
+static double g_kd_gpu_ms = 0.0; // last rt_scene_create: time spent in here (RT_KD_STATS prints it)
+
+static int kd_transform_gpu(const RtSceneDesc* desc, int device, std::vector<std::vector<int>>& lists,
+                            std::vector<int>& new_left, std::vector<int>& axis_of, std::vector<float>& split_of,
+                            std::vector<int>& depth_of, std::vector<KdBox>& cell, int& max_depth,
+                            const KdSplitParams& prm, bool refine, size_t max_nodes)
+{
+    HIP_TRY(hipSetDevice(device));
+    const int nv = desc->n_vertices, nt = desc->n_triangles;
+    std::vector<int> loff(lists.size()), lcnt(lists.size());
+    std::vector<int> flat;
+    for (size_t k = 0; k < lists.size(); ++k) {
+        loff[k] = (int)flat.size(), lcnt[k] = (int)lists[k].size();
+        flat.insert(flat.end(), lists[k].begin(), lists[k].end());
+    }
+    const int pool_cap = (int)std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 22, flat.size() * 256));
+    DevBuf    d_vpos, d_tv, d_pool, d_ctr, d_items, d_results;
+    int       rc;
+    if ((rc = d_vpos.alloc(12 * (size_t)nv)) || (rc = d_tv.alloc(12 * (size_t)nt)) ||
+        (rc = d_pool.alloc(4 * (size_t)pool_cap)) || (rc = d_ctr.alloc(8)))
+        return rc;
+    HIP_TRY(hipMemcpy(d_vpos.p, desc->vertex_pos, 12 * (size_t)nv, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tv.p, desc->tri_vertex, 12 * (size_t)nt, hipMemcpyHostToDevice));
+    if (!flat.empty()) HIP_TRY(hipMemcpy(d_pool.p, flat.data(), 4 * flat.size(), hipMemcpyHostToDevice));
+    int ctr[2] = {(int)flat.size(), 0}; // used, overflow
+    HIP_TRY(hipMemcpy(d_ctr.p, ctr, 8, hipMemcpyHostToDevice));
+    int*   d_used = (int*)d_ctr.p, *d_over = d_used + 1;
+    size_t items_cap = 0;
+    auto   room = [&](size_t n_items, size_t item_bytes, size_t result_bytes) -> int {
+        if (n_items <= items_cap) return RT_OK;
+        d_items.release(), d_results.release();
+        items_cap = n_items + n_items / 2 + 64;
+        int r2;
+        if ((r2 = d_items.alloc(items_cap * std::max(sizeof(KdHandItem), sizeof(KdSplitItem))))) return r2;
+        (void)item_bytes, (void)result_bytes;
+        return d_results.alloc(items_cap * std::max(sizeof(KdHandResult), sizeof(KdSplitResult)));
+    };
+    // ---- hand the inner nodes' triangles down, one level of the input tree after the other ----
+    int in_depth = 0;
+    for (size_t k = 0; k < lists.size(); ++k) in_depth = std::max(in_depth, depth_of[k]);
+    std::vector<std::vector<int>> by_depth((size_t)in_depth + 1);
+    for (size_t k = 0; k < lists.size(); ++k)
+        if (new_left[k] >= 0) by_depth[depth_of[k]].push_back((int)k);
+    std::vector<KdHandItem>   h_items;
+    std::vector<KdHandResult> h_res;
+    for (int d = 0; d <= in_depth; ++d) {
+        h_items.clear();
+        std::vector<int> who;
+        for (int k : by_depth[d]) {
+            if (lcnt[k] == 0) continue; // nothing to hand down: the children keep their own lists
+            KdHandItem it;
+            const int  l = new_left[k], r = l + 1;
+            it.left = cell[l], it.right = cell[r];
+            it.off = loff[k], it.cnt = lcnt[k];
+            it.own_off[0] = loff[l], it.own_cnt[0] = lcnt[l], it.own_off[1] = loff[r], it.own_cnt[1] = lcnt[r];
+            h_items.push_back(it);
+            who.push_back(k);
+        }
+        if (h_items.empty()) continue;
+        if ((rc = room(h_items.size(), sizeof(KdHandItem), sizeof(KdHandResult)))) return rc;
+        HIP_TRY(hipMemcpy(d_items.p, h_items.data(), h_items.size() * sizeof(KdHandItem), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_kd_hand_down, dim3((unsigned)h_items.size()), dim3(KD_BLOCK), 0, 0, (const float*)d_vpos.p,
+                           (const int32_t*)d_tv.p, (const KdHandItem*)d_items.p, (KdHandResult*)d_results.p,
+                           (int32_t*)d_pool.p, d_used, pool_cap, d_over);
+        HIP_TRY(hipGetLastError());
+        h_res.resize(h_items.size());
+        HIP_TRY(hipMemcpy(h_res.data(), d_results.p, h_res.size() * sizeof(KdHandResult), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ctr, d_ctr.p, 8, hipMemcpyDeviceToHost));
+        if (ctr[1]) return 1;
+        for (size_t i = 0; i < who.size(); ++i) {
+            const int k = who[i], l = new_left[k];
+            for (int c = 0; c < 2; ++c) loff[l + c] = h_res[i].off[c], lcnt[l + c] = h_res[i].cnt[c];
+            lcnt[k] = 0;
+        }
+    }
+    // ---- split the leaves that hold many triangles, generation after generation ----
+    std::vector<int> n_new_left = new_left, n_axis = axis_of, n_depth = depth_of;
+    std::vector<float> n_split = split_of;
+    std::vector<KdBox> n_cell = cell;
+    int                n_max_depth = max_depth;
+    if (refine) {
+        std::vector<int> gen;
+        for (size_t k = 0; k < n_new_left.size(); ++k)
+            if (n_new_left[k] < 0) gen.push_back((int)k);
+        std::vector<KdSplitItem>   s_items;
+        std::vector<KdSplitResult> s_res;
+        bool                       full = false;
+        while (!gen.empty() && !full) {
+            std::vector<int> who;
+            s_items.clear();
+            for (int k : gen)
+                if (lcnt[k] > prm.leaf_target && n_depth[k] < 60) {
+                    KdSplitItem it;
+                    it.cell = n_cell[k], it.off = loff[k], it.cnt = lcnt[k];
+                    s_items.push_back(it);
+                    who.push_back(k);
+                }
+            gen.clear();
+            if (s_items.empty()) break;
+            if ((rc = room(s_items.size(), sizeof(KdSplitItem), sizeof(KdSplitResult)))) return rc;
+            HIP_TRY(hipMemcpy(d_items.p, s_items.data(), s_items.size() * sizeof(KdSplitItem), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_kd_split, dim3((unsigned)s_items.size()), dim3(KD_BLOCK), 0, 0, (const float*)d_vpos.p,
+                               (const int32_t*)d_tv.p, (const KdSplitItem*)d_items.p, (KdSplitResult*)d_results.p, prm,
+                               (int32_t*)d_pool.p, d_used, pool_cap, d_over);
+            HIP_TRY(hipGetLastError());
+            s_res.resize(s_items.size());
+            HIP_TRY(hipMemcpy(s_res.data(), d_results.p, s_res.size() * sizeof(KdSplitResult), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ctr, d_ctr.p, 8, hipMemcpyDeviceToHost));
+            if (ctr[1]) return 1;
+            for (size_t i = 0; i < who.size(); ++i) { // in node order, as the host loop walks them
+                if (n_new_left.size() + 2 > max_nodes) {
+                    full = true;
+                    break;
+                }
+                const KdSplitResult& r = s_res[i];
+                if (r.axis < 0) continue;
+                const int k = who[i], l = (int)n_new_left.size();
+                n_new_left[k] = l, n_axis[k] = r.axis, n_split[k] = r.plane;
+                KdBox b[2] = {n_cell[k], n_cell[k]};
+                b[0].hi[r.axis] = (double)r.plane, b[1].lo[r.axis] = (double)r.plane;
+                for (int c = 0; c < 2; ++c) {
+                    n_new_left.push_back(-1), n_depth.push_back(n_depth[k] + 1), n_axis.push_back(0);
+                    n_split.push_back(0.0f), n_cell.push_back(b[c]);
+                    loff.push_back(r.off[c]), lcnt.push_back(r.cnt[c]);
+                    gen.push_back(l + c);
+                }
+                n_max_depth = std::max(n_max_depth, n_depth[k] + 1);
+                lcnt[k] = 0;
+            }
+        }
+    }
+    // ---- the lists back to the host ----
+    HIP_TRY(hipMemcpy(ctr, d_ctr.p, 8, hipMemcpyDeviceToHost));
+    std::vector<int> pool((size_t)ctr[0]);
+    if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), d_pool.p, 4 * pool.size(), hipMemcpyDeviceToHost));
+    new_left.swap(n_new_left), axis_of.swap(n_axis), split_of.swap(n_split), depth_of.swap(n_depth), cell.swap(n_cell);
+    max_depth = n_max_depth;
+    lists.assign(new_left.size(), std::vector<int>());
+    for (size_t k = 0; k < lists.size(); ++k)
+        if (lcnt[k] > 0) lists[k].assign(pool.begin() + loff[k], pool.begin() + loff[k] + lcnt[k]);
+    return 0;
+}
+
 extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out)
 {
     if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
     *out = nullptr;
+    const auto t_create0 = std::chrono::steady_clock::now();
+    double     tree_ms = 0.0;
+    bool       tree_on_gpu = false;
     const int ndev = rt_device_count();
     const bool stats_only = getenv("RT_KD_STATS") != nullptr; // tree diagnostics run without a GPU
     if (ndev <= 0 && !stats_only) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device");
@@ -691,6 +869,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         if (new_left[k] >= 0)
             split_of[k] = desc->nodes[desc->nodes[order[k]].left].bounds[2 * axis_of[k] + 1];
     }
+    const auto t_tree0 = std::chrono::steady_clock::now();
     if (pushdown && nn > 0 && nt > 0) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int v = 0; v < nv; ++v)
@@ -698,54 +877,14 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
                 lo[a] = std::min(lo[a], (double)desc->vertex_pos[3 * v + a]);
                 hi[a] = std::max(hi[a], (double)desc->vertex_pos[3 * v + a]);
             }
-        struct Box {
-            double lo[3], hi[3];
-        };
+        typedef KdBox Box;
         std::vector<Box> cell(order.size());
         for (int a = 0; a < 3; ++a) { // outer cells are open: stand-in far beyond the mesh
             const double ext = hi[a] - lo[a] + 10.0;
             cell[0].lo[a] = lo[a] - ext, cell[0].hi[a] = hi[a] + ext;
         }
         auto overlaps = [&](int t, const Box& b) -> bool {
-            // separating-axis test triangle vs box, box grown a little: conservative
-            double c[3], h[3], v[3][3];
-            for (int a = 0; a < 3; ++a) {
-                c[a] = 0.5 * (b.lo[a] + b.hi[a]);
-                h[a] = 0.5 * (b.hi[a] - b.lo[a]);
-                h[a] += 1e-5 * std::fabs(h[a]) + 1e-5 * (std::fabs(c[a]) + 1.0);
-            }
-            for (int j = 0; j < 3; ++j)
-                for (int a = 0; a < 3; ++a)
-                    v[j][a] = (double)desc->vertex_pos[3 * desc->tri_vertex[3 * t + j] + a] - c[a];
-            for (int a = 0; a < 3; ++a) {
-                const double mn = std::min(v[0][a], std::min(v[1][a], v[2][a]));
-                const double mx = std::max(v[0][a], std::max(v[1][a], v[2][a]));
-                if (mn > h[a] || mx < -h[a]) return false;
-            }
-            double e[3][3];
-            for (int a = 0; a < 3; ++a) {
-                e[0][a] = v[1][a] - v[0][a];
-                e[1][a] = v[2][a] - v[1][a];
-                e[2][a] = v[0][a] - v[2][a];
-            }
-            for (int i = 0; i < 3; ++i)
-                for (int a = 0; a < 3; ++a) { // axis = unit(a) x e[i]
-                    double ax[3] = {0, 0, 0};
-                    const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
-                    ax[a1] = -e[i][a2], ax[a2] = e[i][a1];
-                    const double p0 = ax[0] * v[0][0] + ax[1] * v[0][1] + ax[2] * v[0][2];
-                    const double p1 = ax[0] * v[1][0] + ax[1] * v[1][1] + ax[2] * v[1][2];
-                    const double p2 = ax[0] * v[2][0] + ax[1] * v[2][1] + ax[2] * v[2][2];
-                    const double r = h[0] * std::fabs(ax[0]) + h[1] * std::fabs(ax[1]) + h[2] * std::fabs(ax[2]);
-                    const double mn = std::min(p0, std::min(p1, p2)), mx = std::max(p0, std::max(p1, p2));
-                    const double slack = 1e-9 * (r + std::fabs(mn) + std::fabs(mx)) + 1e-300;
-                    if (mn > r + slack || mx < -r - slack) return false;
-                }
-            double nrm[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
-                             e[0][0] * e[1][1] - e[0][1] * e[1][0]};
-            const double d = nrm[0] * v[0][0] + nrm[1] * v[0][1] + nrm[2] * v[0][2];
-            const double r = h[0] * std::fabs(nrm[0]) + h[1] * std::fabs(nrm[1]) + h[2] * std::fabs(nrm[2]);
-            return std::fabs(d) <= r + 1e-9 * (r + std::fabs(d));
+            return kd_overlaps(desc->vertex_pos, desc->tri_vertex, t, b);
         };
         // RT_KD_REBUILD=1: drop the planes of the input tree and let the refinement below build
         // the whole tree from one root leaf holding every listed triangle.
@@ -765,6 +904,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             cell.resize(1);
             max_depth = 0;
         }
+        // cells of the input tree, top down
         for (size_t k = 0; k < order.size(); ++k) {
             if (new_left[k] < 0) continue;
             const int    axis = depth_of[k] % 3;
@@ -772,6 +912,34 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             const double plane = desc->nodes[desc->nodes[order[k]].left].bounds[2 * axis + 1];
             cell[l] = cell[k], cell[r] = cell[k];
             cell[l].hi[axis] = plane, cell[r].lo[axis] = plane;
+        }
+        const char* rf_env = getenv("RT_KD_REFINE");
+        const bool  refine = !(rf_env && rf_env[0] == '0');
+        const char*  lt_env = getenv("RT_KD_LEAF");
+        const char*  ci_env = getenv("RT_KD_CI");
+        KdSplitParams prm;
+        prm.leaf_target = lt_env ? atoi(lt_env) : 4; // do not split leaves at or below this size
+        prm.c_trav = 1.0, prm.c_isect = ci_env ? atof(ci_env) : 3.0;
+        for (int a = 0; a < 3; ++a) {
+            const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
+            prm.mesh_box.lo[a] = lo[a] - pad, prm.mesh_box.hi[a] = hi[a] + pad;
+        }
+        const size_t max_nodes = 60000; // node indices are 16-bit on the traversal stack
+        // Both steps run on the device (rt_kdrefine.h); RT_KD_GPU=0, or a triangle pool that
+        // overflows, leaves them to the host loops below, which produce the same tree.
+        const char* kg_env = getenv("RT_KD_GPU");
+        bool        on_gpu = ndev > 0 && !(kg_env && kg_env[0] == '0');
+        if (on_gpu) {
+            const int rc_gpu = kd_transform_gpu(desc, device, lists, new_left, axis_of, split_of, depth_of, cell,
+                                                max_depth, prm, refine, max_nodes);
+            if (rc_gpu < 0) return rc_gpu;
+            on_gpu = rc_gpu == 0; // 1: pool overflow, nothing was changed
+            tree_on_gpu = on_gpu;
+        }
+        if (!on_gpu)
+        for (size_t k = 0; k < order.size(); ++k) {
+            if (new_left[k] < 0) continue;
+            const int l = new_left[k], r = l + 1;
             for (int t : lists[k]) {
                 const bool inl = overlaps(t, cell[l]), inr = overlaps(t, cell[r]);
                 if (inl || !inr) lists[l].push_back(t);
@@ -787,23 +955,10 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         // the triangles clipped to the cell ("perfect splits": more empty-space cuts, the node
         // budget runs out, 12.3 vs 12.0 ms per 4K frame), and building the whole tree this way
         // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms).
-        const char* rf_env = getenv("RT_KD_REFINE");
-        if (!(rf_env && rf_env[0] == '0')) {
-            const char*  lt_env = getenv("RT_KD_LEAF");
-            const char*  ci_env = getenv("RT_KD_CI");
-            const int    leaf_target = lt_env ? atoi(lt_env) : 4; // do not split leaves at or below this size
-            const double c_trav = 1.0, c_isect = ci_env ? atof(ci_env) : 3.0;
-            const size_t max_nodes = 60000;     // node indices are 16-bit on the traversal stack
-            Box          mesh_box;
-            for (int a = 0; a < 3; ++a) {
-                const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
-                mesh_box.lo[a] = lo[a] - pad, mesh_box.hi[a] = hi[a] + pad;
-            }
-            auto area = [](const Box& b) {
-                const double dx = std::max(b.hi[0] - b.lo[0], 0.0), dy = std::max(b.hi[1] - b.lo[1], 0.0),
-                             dz = std::max(b.hi[2] - b.lo[2], 0.0);
-                return 2.0 * (dx * dy + dy * dz + dz * dx);
-            };
+        if (refine && !on_gpu) {
+            const int    leaf_target = prm.leaf_target;
+            const double c_trav = prm.c_trav, c_isect = prm.c_isect;
+            const Box    mesh_box = prm.mesh_box;
             for (size_t k = 0; k < lists.size() && lists.size() + 2 <= max_nodes; ++k) {
                 if (new_left[k] >= 0 || (int)lists[k].size() <= leaf_target || depth_of[k] >= 60) continue;
                 Box cb = cell[k]; // the part of the cell rays can come from
@@ -811,41 +966,26 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
                     cb.lo[a] = std::max(cb.lo[a], mesh_box.lo[a]);
                     cb.hi[a] = std::min(cb.hi[a], mesh_box.hi[a]);
                 }
-                const double sa = area(cb);
+                const double sa = kd_area(cb);
                 if (!(sa > 0.0)) continue;
                 const size_t n = lists[k].size();
                 double       best_cost = c_isect * (double)n;
                 int          best_axis = -1;
                 double       best_plane = 0.0;
-                std::vector<double> mins(n), maxs(n), cand;
-                for (int a = 0; a < 3; ++a) {
-                    cand.clear();
+                for (int a = 0; a < 3; ++a)
                     for (size_t i = 0; i < n; ++i) {
-                        const int t = lists[k][i];
-                        double    mn = 1e300, mx = -1e300;
-                        for (int j = 0; j < 3; ++j) {
-                            const double c = desc->vertex_pos[3 * desc->tri_vertex[3 * t + j] + a];
-                            mn = std::min(mn, c), mx = std::max(mx, c);
+                        double mn, mx;
+                        kd_tri_extent(desc->vertex_pos, desc->tri_vertex, lists[k][i], a, mn, mx);
+                        for (int upper = 0; upper < 2; ++upper) { // candidate planes: the triangles' extents
+                            const double pl = upper ? mx : mn;
+                            if (!(pl > cb.lo[a] && pl < cb.hi[a])) continue;
+                            double cost, plane;
+                            if (!kd_split_cost(desc->vertex_pos, desc->tri_vertex, lists[k].data(), (int)n, cb, sa, a,
+                                               pl, c_trav, c_isect, cost, plane))
+                                continue;
+                            if (cost < best_cost) best_cost = cost, best_axis = a, best_plane = plane;
                         }
-                        mins[i] = mn, maxs[i] = mx;
-                        if (mn > cb.lo[a] && mn < cb.hi[a]) cand.push_back(mn);
-                        if (mx > cb.lo[a] && mx < cb.hi[a]) cand.push_back(mx);
                     }
-                    for (double pl : cand) {
-                        const float plf = (float)pl; // the plane the kernel will compare against
-                        if (!((double)plf > cb.lo[a] && (double)plf < cb.hi[a])) continue;
-                        size_t nl = 0, nr = 0;
-                        for (size_t i = 0; i < n; ++i) {
-                            if (mins[i] < (double)plf || (mins[i] == (double)plf && maxs[i] == (double)plf)) ++nl;
-                            if (maxs[i] > (double)plf) ++nr;
-                        }
-                        Box bl = cb, br = cb;
-                        bl.hi[a] = plf, br.lo[a] = plf;
-                        double cost = c_trav + c_isect * (area(bl) * (double)nl + area(br) * (double)nr) / sa;
-                        if (nl == 0 || nr == 0) cost *= 0.8;
-                        if (cost < best_cost) best_cost = cost, best_axis = a, best_plane = (double)plf;
-                    }
-                }
                 if (best_axis < 0) continue;
                 Box bl = cell[k], br = cell[k];
                 bl.hi[best_axis] = best_plane, br.lo[best_axis] = best_plane;
@@ -873,6 +1013,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             }
         }
     }
+    tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tree0).count();
     if (max_depth + 1 > 64)
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: KD tree depth %d exceeds 63", max_depth);
 
@@ -1026,6 +1167,17 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.n_triangles = nt;
     s->d.stack_entries = max_depth + 1;
     s->pushdown = pushdown;
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto     mix = [&](uint32_t v) {
+            for (int b = 0; b < 4; ++b) h = (h ^ ((v >> (8 * b)) & 0xffu)) * 1099511628211ull;
+        };
+        for (const uint2& k : knodes) mix(k.x), mix(k.y);
+        for (size_t i = 0; i < slots.size() / 3; ++i) mix((uint32_t)__builtin_bit_cast(int32_t, slots[3 * i + 2].w));
+        s->tree_hash = h;
+    }
+    s->tree_ms = (float)tree_ms, s->tree_on_gpu = tree_on_gpu ? 1 : 0;
+    s->create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
     for (int i = 0; i < nm; ++i) // raytracing.cpp:177,206: two children only if Ni > 1 and not a mirror
         if (desc->materials[i].Ni > 1.0f && desc->materials[i].illum != 3) s->refractive = true;
     *out = s;
@@ -1040,6 +1192,9 @@ extern "C" int rt_scene_info(const RtScene* s, RtSceneInfo* info)
     info->tree_depth = s->tree_depth;
     info->n_slots = s->d.n_slots;
     info->device_bytes = s->bytes;
+    info->tree_hash = s->tree_hash;
+    info->create_ms = s->create_ms, info->tree_ms = s->tree_ms;
+    info->tree_on_gpu = s->tree_on_gpu, info->reserved = 0;
     return RT_OK;
 }
 
@@ -1165,18 +1320,6 @@ static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n
 // ---------------------------------------------------------------------------
 // batched rays
 // ---------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-    int alloc(size_t bytes)
-    {
-        HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
-        return RT_OK;
-    }
-};
 
 extern "C" int rt_check_hits(RtScene* s, int64_t n, const float* origins, const float* dests,
                              int32_t* tri, float* a, float* b, float* t, float* hitpoint)

@@ -34,6 +34,31 @@ def test_scene_info(P):
     assert i["device_bytes"] > 3846 * 48
 
 
+@pytest.mark.parametrize("name", ["ball", "redballs", "lego", "final", "fin", "checkercube"])
+def test_tree_built_on_the_gpu_equals_the_host_built_one(P, monkeypatch, name):
+    """rt_scene_create hands the inner nodes' triangles down and splits large leaves on the
+    device; RT_KD_GPU=0 runs the same two steps as host loops.  The device tree must be the same
+    one: equal hash over nodes and slots, equal sizes - also with the refinement switched off,
+    and for fin.obj, where the node budget ends the splitting."""
+    hs = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
+    for env in ({}, {"RT_KD_REFINE": "0"}):
+        infos = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RT_KD_GPU", mode)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            infos[mode] = hs.to_gpu(0).info()
+            for k in env:
+                monkeypatch.delenv(k)
+        monkeypatch.delenv("RT_KD_GPU")
+        g, h = infos["1"], infos["0"]
+        assert g["tree_on_gpu"] == 1 and h["tree_on_gpu"] == 0
+        for key in ("tree_hash", "n_nodes", "n_slots", "tree_depth", "device_bytes"):
+            assert g[key] == h[key], (name, env, key, g[key], h[key])
+        print(f"{name} {env}: {g['n_nodes']} nodes; tree steps {g['tree_ms']:.1f} ms on the GPU, "
+              f"{h['tree_ms']:.1f} ms on the host; rt_scene_create {g['create_ms']:.1f} / {h['create_ms']:.1f} ms")
+
+
 def test_normalize_depth_matches_oracle(P, oracle):
     rng = np.random.default_rng(2)
     d = (rng.random(100003, dtype=np.float32) * 0.9 + 0.05).astype(np.float32)
