@@ -1618,8 +1618,10 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
             auto kern = P.soft_n > 0 ? (count ? k_wf_pipeline<true, true> : k_wf_pipeline<false, true>)
                                      : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
-            hipLaunchKernelGGL(kern, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, s->d, P, C[0], slot0[0], n[0],
-                               d_rgb, d_depth, d_tri, flags[0], s->d_ctr);
+            WfLaunch A;
+            A.S = s->d, A.P = P, A.B = C[0], A.slot0 = slot0[0], A.n = n[0], A.pad = 0;
+            A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.centre_hit = flags[0], A.ctr = s->d_ctr;
+            hipLaunchKernelGGL(kern, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, A);
             HIP_TRY(hipGetLastError());
             continue;
         }

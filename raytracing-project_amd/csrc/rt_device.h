@@ -92,7 +92,8 @@ __device__ __forceinline__ unsigned soft_rand(unsigned long long id, unsigned pa
 }
 
 // Destination of soft-shadow sample `si` of light `li` (raytracing.cpp:148-154)
-__device__ __forceinline__ void soft_dest(const float* lights, const float* soft_x, int soft_n, float half,
+template <class FP> // FP: pointer to the light / loop-value arrays, in whatever address space they live
+__device__ __forceinline__ void soft_dest(FP lights, FP soft_x, int soft_n, float half,
                                           float quarter, float radius, int li, int si, unsigned long long id,
                                           unsigned path, float& dx, float& dy, float& dz)
 {
@@ -436,8 +437,8 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
                     const int ns = P.soft_n * P.soft_n * P.soft_n;
                     for (int si = 0; si < ns; ++si) {
                         f3 sd;
-                        soft_dest(P.lights, P.soft_x, P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si,
-                                  id, r.path, sd.x, sd.y, sd.z);
+                        soft_dest(&P.lights[0], &P.soft_x[0], P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li,
+                                  si, id, r.path, sd.x, sd.y, sd.z);
                         ++n_shadow;
                         if (kd_trace<true>(S, so, sd, stk, stride, sh, n_tests, n_nodes)) softShadow += P.soft_w;
                     }
@@ -504,13 +505,14 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
 // RayTracer::raytrace, main.cpp:514-526: bilinear blend of the corner rays;
 // the weights are formed in double and converted to float before they touch
 // the vectors (Vec3D.h:12-18).
-__device__ __forceinline__ void pixel_ray(const DParams& P, double x, double y, f3& o, f3& d)
+template <class PT> // PT: DParams, by value or in the constant address space
+__device__ __forceinline__ void pixel_ray(const PT& P, double x, double y, f3& o, f3& d)
 {
     const double xscale = 1.0 - x / (double)(P.W - 1);
     const double yscale = 1.0 - y / (double)(P.H - 1);
     const float  xs = (float)xscale, xs1 = (float)(1 - xscale), ys = (float)yscale,
                 ys1 = (float)(1 - yscale);
-    const float* c = P.cam;
+    const auto* c = P.cam;
     const f3 o00 = mk3(c[0], c[1], c[2]), d00 = mk3(c[3], c[4], c[5]), o01 = mk3(c[6], c[7], c[8]),
              d01 = mk3(c[9], c[10], c[11]), o10 = mk3(c[12], c[13], c[14]),
              d10 = mk3(c[15], c[16], c[17]), o11 = mk3(c[18], c[19], c[20]),
@@ -523,7 +525,8 @@ __device__ __forceinline__ void pixel_ray(const DParams& P, double x, double y, 
 // shares rank .. rank + span - 1, round after round); inside a
 // tile pixels go by 8x8 blocks so that the 64 lanes of a wave cover a compact
 // screen area.
-__device__ __forceinline__ bool slot_to_pixel(const DParams& P, long long slot, int& x, int& y)
+template <class PT>
+__device__ __forceinline__ bool slot_to_pixel(const PT& P, long long slot, int& x, int& y)
 {
     const int       tile_px = P.tile_w * P.tile_h;
     const long long lt = slot / tile_px;

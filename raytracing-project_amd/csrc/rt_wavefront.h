@@ -430,11 +430,12 @@ __device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lig
 // ---------------------------------------------------------------------------
 // shade: one block per region, one thread per ray of level `level`
 // ---------------------------------------------------------------------------
-template <bool SOFT = false>
-__device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& P, const WfBuffers& B,
+template <bool SOFT = false, class ST = DScene, class PT = DParams>
+__device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const WfBuffers& B,
                                                 const WfRays in, const WfRays out, int r, WfShared* sh,
                                                 unsigned& n_shaded, unsigned& n_child, long long slot0 = 0)
 {
+    const DScene S = wf_scene(S_);
     int&         s_child = sh->child;
     int*         s_sh = sh->sh;
     const int    n = in.cnt[r];
@@ -496,7 +497,7 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                     B.occl[(size_t)li * B.cap + i] = 0;
                     for (int si = 0; si < B.ns; ++si) {
                         float4 dd = make_float4(0, 0, 0, 0);
-                        soft_dest(P.lights, P.soft_x, P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si, id,
+                        soft_dest(&P.lights[0], &P.soft_x[0], P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si, id,
                                   (meta.y >> 16) & 0xffu, dd.x, dd.y, dd.z);
                         B.sh_org[q0 + si] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
                         B.sh_dst[q0 + si] = dd;
@@ -564,8 +565,9 @@ __device__ __forceinline__ void wf_shade_region(const DScene& S, const DParams& 
                 const size_t p = base + pos;
                 out.o_w[p] = make_float4(c_o[c].x, c_o[c].y, c_o[c].z, c_w[c]);
                 out.d_ni[p] = make_float4(c_d[c].x, c_d[c].y, c_d[c].z, n2);
-                const unsigned path = (((meta.y >> 16) & 0x3fu) << 2) | c_kind[c];
-                out.meta[p] = make_uint2(meta.x, (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8) | (path << 16));
+                unsigned my = (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8);
+                if (SOFT) my |= ((((meta.y >> 16) & 0x3fu) << 2) | c_kind[c]) << 16; // the generator's key
+                out.meta[p] = make_uint2(meta.x, my);
             }
         }
     }
@@ -590,10 +592,11 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level, DCounters* ctr)
 // ---------------------------------------------------------------------------
 // resolve: the light loop of raytracing.cpp:110-164 with the shadow queries answered
 // ---------------------------------------------------------------------------
-template <bool SOFT = false>
-__device__ __forceinline__ void wf_resolve_region(const DScene& S, const DParams& P, const WfBuffers& B,
+template <bool SOFT = false, class ST = DScene, class PT = DParams>
+__device__ __forceinline__ void wf_resolve_region(const ST& S_, const PT& P, const WfBuffers& B,
                                                   const WfRays in, int r)
 {
+    const DScene S = wf_scene(S_);
     const int    n = in.cnt[r];
     const size_t base = (size_t)r * B.R;
     const float  shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
@@ -655,7 +658,8 @@ k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
 // ---------------------------------------------------------------------------
 // Block r: centre rays of pixel slots slot0 + [r * S, (r + 1) * S) that lie inside
 // the frame, appended to region r of queue 0.  meta.x = slot - slot0.
-__device__ __forceinline__ void wf_gen_region(const DParams& P, const WfBuffers& B, const WfRays q,
+template <class PT>
+__device__ __forceinline__ void wf_gen_region(const PT& P, const WfBuffers& B, const WfRays q,
                                               long long slot0, int n, DCounters* ctr, int r, WfShared* sh)
 {
     int&         s_n = sh->n;
@@ -693,7 +697,8 @@ k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
 // MSAA > 1, after the centre rays are traced: misses are final pixels; every hit
 // pixel queues its `msaa` sample rays (main.cpp:445-507) into region r of queue 1.
 // Sample index = (slot - slot0) * msaa + s.
-__device__ __forceinline__ void wf_msaa_region(const DParams& P, const WfBuffers& B, const WfRays in,
+template <class PT>
+__device__ __forceinline__ void wf_msaa_region(const PT& P, const WfBuffers& B, const WfRays in,
                                                const WfRays q, long long slot0, float* rgb, float* depth,
                                                int* tri, unsigned char* centre_hit, DCounters* ctr, int r,
                                                WfShared* sh)
@@ -755,7 +760,8 @@ k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth
 // Pixels from sample sums.  MSAA == 1: sample index = slot - slot0.  MSAA > 1:
 // ordered float sum of the samples / msaa, depth = mean of minT over the samples
 // that hit (main.cpp:449-507); only pixels whose centre ray hit.
-__device__ __forceinline__ void wf_finalize_slot(const DParams& P, const WfBuffers& B, long long slot0, int i,
+template <class PT>
+__device__ __forceinline__ void wf_finalize_slot(const PT& P, const WfBuffers& B, long long slot0, int i,
                                                  const unsigned char* __restrict__ centre_hit, float* rgb,
                                                  float* depth, int* tri)
 {
@@ -854,8 +860,8 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
 // region's chain of dependent stages is one trace per level instead of two.  The index
 // space is [closest rays][light 0][light 1]..., each segment padded to whole waves so a
 // wave runs one kind of walk; the closest-hit rays (the longer walks) start first.
-template <bool COUNT, bool SOFT = false>
-__device__ __forceinline__ void wf_trace_merged(const DScene& S, const DParams& P, const WfBuffers& B,
+template <bool COUNT, bool SOFT = false, class PT = DParams>
+__device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, const WfBuffers& B,
                                                 const WfRays next, int n_next, int r, const WfStack& stk,
                                                 unsigned& n_tests, unsigned& n_nodes, unsigned& n_closest,
                                                 unsigned& n_shadow)
@@ -917,73 +923,162 @@ __device__ unsigned long long g_timeline[WF_TL_REGIONS * 16];
 #else
 #define WF_TL(slot) do { } while (0)
 #endif
+// Everything the launch needs, as ONE kernel argument.  The kernel never names the argument:
+// each stage reads the fields it needs from the kernarg segment (constant address space) through
+// a pointer that is laundered in place (wf_args), so the loads cannot be hoisted to the top of
+// the launch and the values live in scalar registers only while their stage runs.  With the
+// three structs as ordinary by-value arguments every pointer in them stayed live across the
+// whole persistent loop (> 100 scalar registers); what did not fit was kept in vector lanes and
+// fetched back with v_readlane - from the moment two more fields were added to WfBuffers also
+// inside the node and triangle loops (16 reloads per iteration, 13.0 vs 12.0 ms per 4K frame).
+struct WfLaunch {
+    DScene         S;
+    DParams        P;
+    WfBuffers      B;
+    long long      slot0;
+    int            n, pad;
+    float*         rgb;
+    float*         depth;
+    int*           tri;
+    unsigned char* centre_hit;
+    DCounters*     ctr;
+};
+typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
+
+// A struct out of the kernarg segment; unused fields vanish, pointer fields stay typed loads from
+// constant memory, which is what lets the compiler treat them as global pointers.  (The copy
+// across address spaces only exists in the device pass; the host pass never runs this.)
+template <class T>
+__device__ __forceinline__ T wf_ld(const __attribute__((address_space(4))) T& src)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return src;
+#else
+    (void)src;
+    return T();
+#endif
+}
+
+__device__ __forceinline__ DScene wf_scene(const DScene& s) { return s; }
+__device__ __forceinline__ DScene wf_scene(const __attribute__((address_space(4))) DScene& s) { return wf_ld(s); }
+
+__device__ __forceinline__ WfLaunchC wf_args()
+{
+    WfLaunchC p = (WfLaunchC)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <bool COUNT, bool SOFT>
 __global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
-k_wf_pipeline(DScene S, DParams P, WfBuffers B, long long slot0, int n, float* rgb, float* depth, int* tri,
-              unsigned char* centre_hit, DCounters* ctr)
+k_wf_pipeline(WfLaunch)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
     __shared__ WfShared sh;
-    const WfStack       stk = wf_stack(S, s_mem);
     unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0, n_shaded = 0, n_child = 0;
-    const size_t        ns = (size_t)B.n_samples;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) sh.region = atomicAdd(&B.ctr->head_region, 1);
+        if (threadIdx.x == 0) sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
         __syncthreads();
         const int r = sh.region;
-        if (r >= B.G) break;
-        const size_t base = (size_t)r * B.R;
+        if (r >= wf_args()->B.G) break;
         WF_TL(0);
 #ifdef WF_TIMELINE
         if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + 15] = blockIdx.x;
 #endif
-        for (int j = threadIdx.x; j < B.S * P.msaa; j += WF_BLOCK) { // this region's colour sums
-            const size_t k = (size_t)r * B.S * P.msaa + j;
-            B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
+        {
+            const WfLaunchC A = wf_args();
+            const WfBuffers B = wf_ld(A->B);
+            const size_t    ns = (size_t)B.n_samples;
+            const int       msaa = A->P.msaa;
+            for (int j = threadIdx.x; j < B.S * msaa; j += WF_BLOCK) { // this region's colour sums
+                const size_t k = (size_t)r * B.S * msaa + j;
+                B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
+            }
+            wf_gen_region(A->P, B, wf_ld(A->B.rays[0]), A->slot0, A->n, A->ctr, r, &sh);
         }
-        wf_gen_region(P, B, B.rays[0], slot0, n, ctr, r, &sh);
         __syncthreads();
-        wf_trace_region<false, COUNT>(S, B.rays[0].o_w, B.rays[0].d_ni, mk3(0, 0, 0), B.rays[0].cnt[r], base,
-                                      B.rays[0].hits, nullptr, stk, n_tests, n_nodes, n_closest);
+        {
+            const WfLaunchC A = wf_args();
+            const DScene    S = wf_ld(A->S);
+            const WfRays    q0 = wf_ld(A->B.rays[0]);
+            wf_trace_region<false, COUNT>(S, q0.o_w, q0.d_ni, mk3(0, 0, 0), q0.cnt[r], (size_t)r * A->B.R, q0.hits,
+                                          nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
+        }
         __syncthreads();
         WF_TL(1);
         int q = 0;
-        if (P.msaa > 1) {
-            wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, r, &sh);
+        if (wf_args()->P.msaa > 1) {
+            {
+                const WfLaunchC A = wf_args();
+                const WfBuffers B = wf_ld(A->B);
+                wf_msaa_region(A->P, B, wf_ld(A->B.rays[0]), wf_ld(A->B.rays[1]), A->slot0, A->rgb, A->depth, A->tri, A->centre_hit,
+                               A->ctr, r, &sh);
+            }
             __syncthreads();
             q = 1;
-            wf_trace_region<false, COUNT>(S, B.rays[1].o_w, B.rays[1].d_ni, mk3(0, 0, 0), B.rays[1].cnt[r], base,
-                                          B.rays[1].hits, nullptr, stk, n_tests, n_nodes, n_closest);
+            {
+                const WfLaunchC A = wf_args();
+                const DScene    S = wf_ld(A->S);
+                const WfRays    q1 = wf_ld(A->B.rays[1]);
+                wf_trace_region<false, COUNT>(S, q1.o_w, q1.d_ni, mk3(0, 0, 0), q1.cnt[r], (size_t)r * A->B.R,
+                                              q1.hits, nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
+            }
             __syncthreads();
         }
         WF_TL(2);
         // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
-        if (B.rays[q].cnt[r] > 0) {
-            wf_shade_region<SOFT>(S, P, B, B.rays[q], B.rays[q ^ 1], r, &sh, n_shaded, n_child, slot0);
+        if (wf_args()->B.rays[q].cnt[r] > 0) {
+            {
+                const WfLaunchC A = wf_args();
+                const WfBuffers B = wf_ld(A->B);
+                wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), wf_ld(A->B.rays[q ^ 1]), r, &sh, n_shaded, n_child,
+                                      A->slot0);
+            }
             __syncthreads();
             for (int level = 0; level < 5; ++level, q ^= 1) {
-                const WfRays in = B.rays[q], out = B.rays[q ^ 1];
-                const int    n_out = out.cnt[r];
-                wf_trace_merged<COUNT, SOFT>(S, P, B, out, n_out, r, stk, n_tests, n_nodes, n_closest, n_shadow);
+                int n_out;
+                {
+                    const WfLaunchC A = wf_args();
+                    const DScene    S = wf_ld(A->S);
+                    const WfBuffers B = wf_ld(A->B);
+                    const WfRays    out = wf_ld(A->B.rays[q ^ 1]);
+                    n_out = out.cnt[r];
+                    wf_trace_merged<COUNT, SOFT>(S, A->P, B, out, n_out, r, wf_stack(S, s_mem), n_tests, n_nodes,
+                                                 n_closest, n_shadow);
+                }
                 __syncthreads();
                 WF_TL(3 + 2 * level);
-                wf_resolve_region<SOFT>(S, P, B, in, r);
+                {
+                    const WfLaunchC A = wf_args();
+                    const WfBuffers B = wf_ld(A->B);
+                    wf_resolve_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), r);
+                }
                 if (n_out == 0) break;
                 __syncthreads(); // resolve still reads the queue the next shade writes its children to
-                wf_shade_region<SOFT>(S, P, B, out, in, r, &sh, n_shaded, n_child, slot0);
+                {
+                    const WfLaunchC A = wf_args();
+                    const WfBuffers B = wf_ld(A->B);
+                    wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q ^ 1]), wf_ld(A->B.rays[q]), r, &sh, n_shaded,
+                                          n_child, A->slot0);
+                }
                 __syncthreads();
                 WF_TL(4 + 2 * level);
             }
             __syncthreads();
         }
         WF_TL(13);
-        for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
-            const int i = r * B.S + j;
-            if (i < n) wf_finalize_slot(P, B, slot0, i, centre_hit, rgb, depth, tri);
+        {
+            const WfLaunchC A = wf_args();
+            const WfBuffers B = wf_ld(A->B);
+            for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
+                const int i = r * B.S + j;
+                if (i < A->n) wf_finalize_slot(A->P, B, A->slot0, i, A->centre_hit, A->rgb, A->depth, A->tri);
+            }
         }
         WF_TL(14);
     }
+    DCounters* ctr = wf_args()->ctr;
     for (int s = 32; s > 0; s >>= 1) {
         n_tests += __shfl_down(n_tests, s);
         n_nodes += __shfl_down(n_nodes, s);
