@@ -1578,7 +1578,9 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     if (s->cfg.region > 0) S = s->cfg.region;
     S = std::max(64, std::min(4096, (S / 64) * 64));
     if (single) n_pipes = 1;
-    WfPlan pl = wf_plan(s, P, (n_slots + n_pipes - 1) / n_pipes, n_pipes, S);
+    // the single launch keeps one set of buffers per resident block, whatever the size of the frame
+    const long long plan_slots = single ? std::min(n_slots, (long long)s->wf_grid_pipe * S) : (n_slots + n_pipes - 1) / n_pipes;
+    WfPlan pl = wf_plan(s, P, plan_slots, n_pipes, S);
     size_t off[24];
     const size_t per_pipe = wf_chunk_bytes(pl, L, off);
     const size_t need = per_pipe * n_pipes;
@@ -1604,7 +1606,18 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         HIP_TRY(hipStreamWaitEvent(s->wf_stream[k], s->wf_fork, 0));
         wf_carve((unsigned char*)s->wf_mem + per_pipe * k, pl, &C[k], &flags[k], off);
     }
-    for (long long round0 = 0; round0 < n_slots; round0 += pl.chunk_slots * n_pipes) {
+    if (single) {
+        hipStream_t st = s->wf_stream[0];
+        HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
+        auto kern = P.soft_n > 0 ? (count ? k_wf_pipeline<true, true> : k_wf_pipeline<false, true>)
+                                 : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
+        WfLaunch A;
+        A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
+        A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.centre_hit = flags[0], A.ctr = s->d_ctr;
+        hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), s->wf_lds, st, A); // pl.G <= resident blocks
+        HIP_TRY(hipGetLastError());
+    }
+    for (long long round0 = 0; !single && round0 < n_slots; round0 += pl.chunk_slots * n_pipes) {
         long long slot0[WF_MAX_PIPES];
         int       n[WF_MAX_PIPES];
         int       live = 0;
@@ -1612,18 +1625,6 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             slot0[k] = round0 + pl.chunk_slots * k;
             n[k] = (int)std::max<long long>(0, std::min<long long>(pl.chunk_slots, n_slots - slot0[k]));
             if (n[k] > 0) live = k + 1;
-        }
-        if (single) {
-            hipStream_t st = s->wf_stream[0];
-            HIP_TRY(hipMemsetAsync(C[0].ctr, 0, sizeof(WfCounters), st));
-            auto kern = P.soft_n > 0 ? (count ? k_wf_pipeline<true, true> : k_wf_pipeline<false, true>)
-                                     : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
-            WfLaunch A;
-            A.S = s->d, A.P = P, A.B = C[0], A.slot0 = slot0[0], A.n = n[0], A.pad = 0;
-            A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.centre_hit = flags[0], A.ctr = s->d_ctr;
-            hipLaunchKernelGGL(kern, dim3(s->wf_grid_pipe), dim3(WF_BLOCK), s->wf_lds, st, A);
-            HIP_TRY(hipGetLastError());
-            continue;
         }
         WfBuffers V[WF_MAX_PIPES]; // this round's view (ray queues get swapped for MSAA)
         for (int k = 0; k < live; ++k) {

@@ -936,7 +936,7 @@ struct WfLaunch {
     DParams        P;
     WfBuffers      B;
     long long      slot0;
-    int            n, pad;
+    int            n, n_regions; // pixel slots of the frame part, regions of B.S slots they make
     float*         rgb;
     float*         depth;
     int*           tri;
@@ -981,7 +981,15 @@ k_wf_pipeline(WfLaunch)
         if (threadIdx.x == 0) sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
         __syncthreads();
         const int r = sh.region;
-        if (r >= wf_args()->B.G) break;
+        if (r >= wf_args()->n_regions) break;
+        // The workspace has one set of queues, colour sums and flags per block, not per region: the
+        // block runs region r as "region qr" of the buffers, with the first pixel slot and the slot
+        // count shifted to match.  Consecutive regions of a block reuse the same few hundred KB,
+        // which stay in the L2 of its XCD instead of streaming through HBM (11.5 -> 11.1 ms per 4K
+        // frame), and the workspace does not grow with the frame.
+        const int qr = blockIdx.x;
+#define WF_SLOT0(A) ((A)->slot0 + (long long)(r - qr) * (A)->B.S)
+#define WF_N(A) ((A)->n + (qr - r) * (A)->B.S)
         WF_TL(0);
 #ifdef WF_TIMELINE
         if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + 15] = blockIdx.x;
@@ -992,17 +1000,17 @@ k_wf_pipeline(WfLaunch)
             const size_t    ns = (size_t)B.n_samples;
             const int       msaa = A->P.msaa;
             for (int j = threadIdx.x; j < B.S * msaa; j += WF_BLOCK) { // this region's colour sums
-                const size_t k = (size_t)r * B.S * msaa + j;
+                const size_t k = (size_t)qr * B.S * msaa + j;
                 B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
             }
-            wf_gen_region(A->P, B, wf_ld(A->B.rays[0]), A->slot0, A->n, A->ctr, r, &sh);
+            wf_gen_region(A->P, B, wf_ld(A->B.rays[0]), WF_SLOT0(A), WF_N(A), A->ctr, qr, &sh);
         }
         __syncthreads();
         {
             const WfLaunchC A = wf_args();
             const DScene    S = wf_ld(A->S);
             const WfRays    q0 = wf_ld(A->B.rays[0]);
-            wf_trace_region<false, COUNT>(S, q0.o_w, q0.d_ni, mk3(0, 0, 0), q0.cnt[r], (size_t)r * A->B.R, q0.hits,
+            wf_trace_region<false, COUNT>(S, q0.o_w, q0.d_ni, mk3(0, 0, 0), q0.cnt[qr], (size_t)qr * A->B.R, q0.hits,
                                           nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
         }
         __syncthreads();
@@ -1012,8 +1020,8 @@ k_wf_pipeline(WfLaunch)
             {
                 const WfLaunchC A = wf_args();
                 const WfBuffers B = wf_ld(A->B);
-                wf_msaa_region(A->P, B, wf_ld(A->B.rays[0]), wf_ld(A->B.rays[1]), A->slot0, A->rgb, A->depth, A->tri, A->centre_hit,
-                               A->ctr, r, &sh);
+                wf_msaa_region(A->P, B, wf_ld(A->B.rays[0]), wf_ld(A->B.rays[1]), WF_SLOT0(A), A->rgb, A->depth, A->tri, A->centre_hit,
+                               A->ctr, qr, &sh);
             }
             __syncthreads();
             q = 1;
@@ -1021,19 +1029,19 @@ k_wf_pipeline(WfLaunch)
                 const WfLaunchC A = wf_args();
                 const DScene    S = wf_ld(A->S);
                 const WfRays    q1 = wf_ld(A->B.rays[1]);
-                wf_trace_region<false, COUNT>(S, q1.o_w, q1.d_ni, mk3(0, 0, 0), q1.cnt[r], (size_t)r * A->B.R,
+                wf_trace_region<false, COUNT>(S, q1.o_w, q1.d_ni, mk3(0, 0, 0), q1.cnt[qr], (size_t)qr * A->B.R,
                                               q1.hits, nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
             }
             __syncthreads();
         }
         WF_TL(2);
         // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
-        if (wf_args()->B.rays[q].cnt[r] > 0) {
+        if (wf_args()->B.rays[q].cnt[qr] > 0) {
             {
                 const WfLaunchC A = wf_args();
                 const WfBuffers B = wf_ld(A->B);
-                wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), wf_ld(A->B.rays[q ^ 1]), r, &sh, n_shaded, n_child,
-                                      A->slot0);
+                wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), wf_ld(A->B.rays[q ^ 1]), qr, &sh, n_shaded, n_child,
+                                      WF_SLOT0(A));
             }
             __syncthreads();
             for (int level = 0; level < 5; ++level, q ^= 1) {
@@ -1043,8 +1051,8 @@ k_wf_pipeline(WfLaunch)
                     const DScene    S = wf_ld(A->S);
                     const WfBuffers B = wf_ld(A->B);
                     const WfRays    out = wf_ld(A->B.rays[q ^ 1]);
-                    n_out = out.cnt[r];
-                    wf_trace_merged<COUNT, SOFT>(S, A->P, B, out, n_out, r, wf_stack(S, s_mem), n_tests, n_nodes,
+                    n_out = out.cnt[qr];
+                    wf_trace_merged<COUNT, SOFT>(S, A->P, B, out, n_out, qr, wf_stack(S, s_mem), n_tests, n_nodes,
                                                  n_closest, n_shadow);
                 }
                 __syncthreads();
@@ -1052,15 +1060,15 @@ k_wf_pipeline(WfLaunch)
                 {
                     const WfLaunchC A = wf_args();
                     const WfBuffers B = wf_ld(A->B);
-                    wf_resolve_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), r);
+                    wf_resolve_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), qr);
                 }
                 if (n_out == 0) break;
                 __syncthreads(); // resolve still reads the queue the next shade writes its children to
                 {
                     const WfLaunchC A = wf_args();
                     const WfBuffers B = wf_ld(A->B);
-                    wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q ^ 1]), wf_ld(A->B.rays[q]), r, &sh, n_shaded,
-                                          n_child, A->slot0);
+                    wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q ^ 1]), wf_ld(A->B.rays[q]), qr, &sh, n_shaded,
+                                          n_child, WF_SLOT0(A));
                 }
                 __syncthreads();
                 WF_TL(4 + 2 * level);
@@ -1072,12 +1080,14 @@ k_wf_pipeline(WfLaunch)
             const WfLaunchC A = wf_args();
             const WfBuffers B = wf_ld(A->B);
             for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
-                const int i = r * B.S + j;
-                if (i < A->n) wf_finalize_slot(A->P, B, A->slot0, i, A->centre_hit, A->rgb, A->depth, A->tri);
+                const int i = qr * B.S + j;
+                if (i < WF_N(A)) wf_finalize_slot(A->P, B, WF_SLOT0(A), i, A->centre_hit, A->rgb, A->depth, A->tri);
             }
         }
         WF_TL(14);
     }
+#undef WF_SLOT0
+#undef WF_N
     DCounters* ctr = wf_args()->ctr;
     for (int s = 32; s > 0; s >>= 1) {
         n_tests += __shfl_down(n_tests, s);
