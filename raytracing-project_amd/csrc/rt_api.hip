@@ -1499,9 +1499,9 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
     take(cap * 16 * 2);                        // 8 hits, one set per queue
     take(cap * 4);                             // 9 wlocal
     take(cap * 16 * (size_t)L * pl.ns);        // 10 sh_org
-    take(G * 4 * (size_t)L);                   // 11 sh_cnt
+    take(G * 4);                               // 11 sh_cnt
     take(cap * (size_t)L);                     // 12 occl
-    take(((G + 1) + (G * (size_t)L + 1)) * 4); // 13 prefix
+    take((G + 1) * 2 * 4);                     // 13 prefix
     take(ns * 8 * 3);                          // 14 acc
     take(ns * 4);                              // 15 s_minT
     take(ns * 4);                              // 16 s_tri
@@ -1544,7 +1544,7 @@ static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hi
     const int te = timing_begin(s, K_TRACE_CLOSEST, st);
     hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
                        (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
-                       (const int*)C.rays[q].cnt, (const int*)C.prefix, C.G, C.G, C.R, C.cap, head, C.rays[q].hits,
+                       (const int*)C.rays[q].cnt, (const int*)C.prefix, 1, C.G, C.R, C.cap, head, C.rays[q].hits,
                        (unsigned char*)nullptr, s->d_ctr);
     timing_end(s, te, st);
 }
@@ -1634,7 +1634,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             HIP_TRY(hipMemsetAsync(V[k].acc, 0, (size_t)pl.n_samples * 8 * 3, st));
             hipLaunchKernelGGL(k_wf_gen_centre, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], n[k],
                                s->d_ctr);
-            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0, 0);
+            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0);
         }
         for (int k = 0; k < live; ++k)
             wf_launch_trace(s, V[k], 0, &V[k].ctr->head_rays[WF_MAX_DEPTH], s->wf_stream[k]);
@@ -1646,7 +1646,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                 hipLaunchKernelGGL(k_wf_msaa_emit, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], d_rgb,
                                    d_depth, d_tri, flags[k], s->d_ctr);
                 std::swap(V[k].rays[0], V[k].rays[1]);
-                hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0, 0);
+                hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0);
             }
             traced0 = false;
         }
@@ -1657,8 +1657,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                 if (level > 0 || !traced0) wf_launch_trace(s, V[k], q, &V[k].ctr->head_rays[level], st);
                 hipLaunchKernelGGL(k_wf_shade, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level, s->d_ctr);
                 // work lists of the next level's rays (block 0) and of this level's shadow queues
-                hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, V[k], q ^ 1,
-                                   P.n_lights);
+                hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, V[k], q ^ 1);
             }
             for (int k = 0; k < live; ++k) {
                 hipStream_t st = s->wf_stream[k];
@@ -1667,7 +1666,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                     hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st,
                                        s->d, (const float4*)V[k].sh_org, (const float4*)nullptr,
                                        (const DParams*)s->d_params, (const int*)V[k].sh_cnt,
-                                       (const int*)(V[k].prefix + (V[k].G + 1)), V[k].G, P.n_lights * V[k].G,
+                                       (const int*)(V[k].prefix + (V[k].G + 1)), P.n_lights, V[k].G,
                                        V[k].R, V[k].cap, &V[k].ctr->head_shadow[level][0], (float4*)nullptr,
                                        V[k].occl, s->d_ctr);
                     timing_end(s, ta, st);

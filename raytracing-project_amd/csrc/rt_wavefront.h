@@ -64,7 +64,7 @@ struct WfShared {
     int child;                  // rays appended to the next level's region
     int n;                      // rays appended by the camera stages
     int region;                 // k_wf_pipeline: the region the block works on
-    int sh[RT_MAX_LIGHTS_DEV];  // shadow rays appended per light
+    int sh;                     // shadow rays appended
 };
 
 // One queue of rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
@@ -80,11 +80,12 @@ struct WfRays {
 struct WfBuffers {
     WfRays         rays[2];   // ping-pong between levels
     float*         wlocal;    // per ray slot: weight of the hit's own colour (0 for a miss)
-    float4*        sh_org;    // [light][cap * ns]: shadow ray origin xyz, bits(ray slot)
-    float4*        sh_dst;    // [light][cap * ns]: soft shadows only, the sample's destination
-    int*           sh_cnt;    // [light][G]
+    float4*        sh_org;    // [cap * lights * ns]: shadow ray origin xyz, bits(light << 24 | ray slot in its region);
+                              // one queue per region for all lights, R * lights * ns entries each
+    float4*        sh_dst;    // [cap * lights * ns]: soft shadows only, the sample's destination
+    int*           sh_cnt;    // [G]
     unsigned char* occl;      // [light][cap]: 1 = occluded (soft shadows: occluded samples), indexed by ray slot
-    int*           prefix;    // [G + 1] for the ray queue, then [lights * G + 1] for the shadow queues
+    int*           prefix;    // [G + 1] for the ray queue, then [G + 1] for the shadow queue
     long long*     acc;       // [3][n_samples] fixed-point colour sums
     float*         s_minT;    // per sample: t of the camera ray's hit (FLT_MAX = miss)
     int*           s_tri;     // per sample: triangle of the camera ray's hit
@@ -100,12 +101,11 @@ struct WfBuffers {
 // work lists and the persistent trace kernels
 // ---------------------------------------------------------------------------
 // Work-item prefix sums: item counts ceil(cnt / 64) per region, exclusive scan.
-// Block 0: the G regions of ray queue `q`.  Block 1: the n_lights * G regions of the
-// shadow queues (light-major), one list for all lights.
-__global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int n_lights)
+// Block 0: the G regions of ray queue `q`.  Block 1: the G regions of the shadow queue.
+__global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q)
 {
     __shared__ int s_part[1024];
-    const int      n = blockIdx.x == 0 ? B.G : n_lights * B.G;
+    const int      n = B.G;
     const int*     cnt = blockIdx.x == 0 ? B.rays[q].cnt : B.sh_cnt;
     int*           out = blockIdx.x == 0 ? B.prefix : B.prefix + (B.G + 1);
     const int      per = (n + 1023) / 1024;
@@ -279,16 +279,15 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 // as their rays finish was measured: it keeps more lanes busy but scatters the lanes
 // over the tree, and the extra cache lines per load cost more than the idle lanes.)
 //   ANY = false: queue of a level -> hit records.
-//   ANY = true : shadow queues of all lights of a level, one region list after the other
-//                (work list of n_lights * G regions); every ray of light li ends at
-//                lights[li] -> occlusion bytes.
+//   ANY = true : shadow queue of a level (regions of R * n_lights slots); every ray ends at
+//                the light its record names -> occlusion bytes.
 // LDS: per-thread stacks of ushort node indices.  (Keeping the top of the node array in
 // LDS too was measured: 27.7 ms per 4K frame without it, 29.9 / 32.5 / 39.5 ms with 32 / 48 /
 // 64 KB per block - the nodes stay in the vector L1 and the LDS costs occupancy.)
 template <bool ANY>
 __global__ void __launch_bounds__(WF_BLOCK)
 k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ d_ni, DParams const* lights,
-           const int* __restrict__ cnt, const int* __restrict__ prefix, int G, int n_regions, int R, int cap,
+           const int* __restrict__ cnt, const int* __restrict__ prefix, int n_lights, int n_regions, int R, int cap,
            int* head, float4* hits, unsigned char* occl, DCounters* ctr)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
@@ -318,11 +317,10 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
             }
             const int idx = (t - prefix[r]) * 64 + lane;
             if (idx >= cnt[r]) continue;
-            const int    li = ANY ? r / G : 0; // shadow regions are numbered light-major
-            const int    rr = r - li * G;
-            const size_t i = (size_t)li * cap + (size_t)rr * R + idx;
+            const size_t i = (size_t)r * R * (ANY ? n_lights : 1) + idx;
             const float4 ow = o_w[i];
             const f3     o = mk3(ow.x, ow.y, ow.z);
+            const int    li = ANY ? (int)((unsigned)__float_as_int(ow.w) >> 24) : 0;
             f3           dst;
             if (ANY) dst = mk3(lights->lights[3 * li], lights->lights[3 * li + 1], lights->lights[3 * li + 2]);
             else {
@@ -332,7 +330,7 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
             HitRec h;
             ++n_rays;
             const bool got = wf_traverse<ANY>(S, stk, o, dst - o, h, n_tests, n_nodes);
-            if (ANY) occl[(size_t)li * cap + __float_as_int(ow.w)] = got ? 1 : 0;
+            if (ANY) occl[(size_t)li * cap + (size_t)r * R + (__float_as_int(ow.w) & 0xffffff)] = got ? 1 : 0;
             else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
         }
     }
@@ -437,11 +435,11 @@ __device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const
 {
     const DScene S = wf_scene(S_);
     int&         s_child = sh->child;
-    int*         s_sh = sh->sh;
+    int&         s_sh = sh->sh;
     const int    n = in.cnt[r];
     const size_t base = (size_t)r * B.R;
-    if (threadIdx.x == 0) s_child = 0;
-    if ((int)threadIdx.x < P.n_lights) s_sh[threadIdx.x] = 0;
+    const size_t sbase = base * P.n_lights * (SOFT ? B.ns : 1); // the region's shadow queue
+    if (threadIdx.x == 0) s_child = 0, s_sh = 0;
     __syncthreads();
     const int n_pad = (n + 63) & ~63; // whole waves iterate together: the ballots need every lane
     for (int j = threadIdx.x; j < n_pad; j += WF_BLOCK) {
@@ -465,7 +463,8 @@ __device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const
         if (valid && !is_hit) // raytracing.cpp:74
             wf_acc_add(B, meta.x, mk3(P.bg[0], P.bg[1], P.bg[2]) * w, shared);
         if (is_hit) wf_surface(S, o, dst, hit, s), ++n_shaded;
-        // ---- shadow rays, one queue per light ----
+        // ---- shadow rays: one queue for all lights (a wave of shadow rays then is full whatever
+        // the share of each light; rays of one light and one wave of hits stay neighbours) ----
         float shadowMax = 0.0f;
         for (int li = 0; li < P.n_lights; ++li) {
             bool cast = false;
@@ -482,24 +481,25 @@ __device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const
                 if (!SOFT && shadowMax == 1.0f) cast = false;
                 shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax;
             }
-            const int pos = wf_append(&s_sh[li], cast, SOFT ? B.ns : 1);
+            const int pos = wf_append(&s_sh, cast, SOFT ? B.ns : 1);
             if (cast) {
-                const f3 so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
+                const f3  so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
+                const int tag = (li << 24) | j;
                 if (!SOFT) {
-                    B.sh_org[(size_t)li * B.cap + base + pos] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+                    B.sh_org[sbase + pos] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
                 } else { // raytracing.cpp:145-160: ns rays towards jittered points around the light
                     const int slot = P.msaa == 1 ? (int)meta.x : (int)(meta.x / (unsigned)P.msaa);
                     const int sn = P.msaa == 1 ? 0 : (int)(meta.x % (unsigned)P.msaa) + 1;
                     int       px = 0, py = 0;
                     slot_to_pixel(P, slot0 + slot, px, py);
                     const unsigned long long id = ((unsigned long long)py * P.W + px) * 32 + sn;
-                    const size_t             q0 = ((size_t)li * B.cap + base) * B.ns + pos;
+                    const size_t             q0 = sbase + pos;
                     B.occl[(size_t)li * B.cap + i] = 0;
                     for (int si = 0; si < B.ns; ++si) {
                         float4 dd = make_float4(0, 0, 0, 0);
                         soft_dest(&P.lights[0], &P.soft_x[0], P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si, id,
                                   (meta.y >> 16) & 0xffu, dd.x, dd.y, dd.z);
-                        B.sh_org[q0 + si] = make_float4(so.x, so.y, so.z, __int_as_float((int)i));
+                        B.sh_org[q0 + si] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
                         B.sh_dst[q0 + si] = dd;
                     }
                 }
@@ -573,7 +573,7 @@ __device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const
     }
     __syncthreads();
     if (threadIdx.x == 0) out.cnt[r] = min(s_child, B.R);
-    if ((int)threadIdx.x < P.n_lights) B.sh_cnt[(size_t)threadIdx.x * B.G + r] = s_sh[threadIdx.x];
+    if (threadIdx.x == 0) B.sh_cnt[r] = s_sh;
 }
 
 __global__ void __launch_bounds__(WF_BLOCK)
@@ -858,8 +858,8 @@ __device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* _
 // Shadow queries of one level and closest-hit queries of the next in one pass: both sets
 // of rays come out of the same shade stage and neither needs the other's answers, so a
 // region's chain of dependent stages is one trace per level instead of two.  The index
-// space is [closest rays][light 0][light 1]..., each segment padded to whole waves so a
-// wave runs one kind of walk; the closest-hit rays (the longer walks) start first.
+// space is [closest rays][shadow rays], each segment padded to whole waves so a wave runs one
+// kind of walk; the closest-hit rays (the longer walks) start first.
 template <bool COUNT, bool SOFT = false, class PT = DParams>
 __device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, const WfBuffers& B,
                                                 const WfRays next, int n_next, int r, const WfStack& stk,
@@ -868,8 +868,9 @@ __device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, co
 {
     const size_t base = (size_t)r * B.R;
     const int    seg_c = (n_next + 63) & ~63;
-    int          total = seg_c;
-    for (int li = 0; li < P.n_lights; ++li) total += (B.sh_cnt[(size_t)li * B.G + r] + 63) & ~63;
+    const int    n_sh = B.sh_cnt[r];
+    const int    total = seg_c + n_sh;
+    const size_t sbase = base * P.n_lights * (SOFT ? B.ns : 1);
     for (int i = threadIdx.x; i < total; i += WF_BLOCK) {
         if (i < seg_c) {
             if (i >= n_next) continue;
@@ -881,16 +882,11 @@ __device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, co
             const bool got = wf_traverse<false, COUNT>(S, stk, o, mk3(dn.x, dn.y, dn.z) - o, h, n_tests, n_nodes);
             next.hits[k] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
         } else {
-            int j = i - seg_c, li = 0, n_li = B.sh_cnt[r];
-            while (j >= ((n_li + 63) & ~63)) { // wave-uniform: segments are whole waves
-                j -= (n_li + 63) & ~63;
-                ++li;
-                n_li = B.sh_cnt[(size_t)li * B.G + r];
-            }
-            if (j >= n_li) continue;
-            const size_t qi = SOFT ? ((size_t)li * B.cap + base) * B.ns + j : (size_t)li * B.cap + base + j;
+            const size_t qi = sbase + (i - seg_c);
             const float4 ow = B.sh_org[qi];
             const f3     o = mk3(ow.x, ow.y, ow.z);
+            const int    li = (int)((unsigned)__float_as_int(ow.w) >> 24);
+            const size_t hit_slot = base + (size_t)(__float_as_int(ow.w) & 0xffffff);
             f3           l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
             if (SOFT) {
                 const float4 dd = B.sh_dst[qi];
@@ -900,9 +896,9 @@ __device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, co
             ++n_shadow;
             const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, n_tests, n_nodes);
             if (!SOFT) {
-                B.occl[(size_t)li * B.cap + __float_as_int(ow.w)] = got ? 1 : 0;
+                B.occl[(size_t)li * B.cap + hit_slot] = got ? 1 : 0;
             } else if (got) { // count in the hit's byte (at most 216 samples): add into its 32-bit word
-                const size_t b = (size_t)li * B.cap + (size_t)__float_as_int(ow.w);
+                const size_t b = (size_t)li * B.cap + hit_slot;
                 atomicAdd((unsigned*)(B.occl + (b & ~(size_t)3)), 1u << (8 * (unsigned)(b & 3)));
             }
         }
