@@ -503,6 +503,9 @@ struct RtScene {
     bool       refractive = false; // some material can spawn two child rays
     int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
+    int        wf_cus = 0;                              // compute units of the device
+    size_t     wf_single_lds = 0;                       // last LDS size the single launch was sized for, and
+    int        wf_single_grid = 0;                      // the blocks that stay resident with it
     void*      d_stk_spill = nullptr; // deep traversal stack entries of the wavefront kernels
     void*      wf_mem = nullptr;   // one allocation carved into the queues
     void*      d_params = nullptr; // device copy of the frame's DParams (light positions)
@@ -1411,7 +1414,11 @@ static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
 // ---------------------------------------------------------------------------
 // wavefront renderer (rt_wavefront.h)
 // ---------------------------------------------------------------------------
-#define WF_STACK_LDS 12 // traversal stack entries per thread kept in LDS
+// Traversal stack entries per thread kept in LDS.  Measured per 4K frame: 10.59 / 10.53 / 10.55 / 10.69 ms
+// with 12 / 10 / 8 / 6; six leave room for the colour sums of a region of 512 samples beside
+// them at seven blocks per CU (seven entries: six blocks, 10.8 vs 10.3 ms).
+#define WF_STACK_LDS 6
+#define WF_ACC_SAMPLES 512 // samples per region the single launch holds colour sums for (24 bytes each, LDS)
 #define WF_WORKSPACE_BUDGET ((size_t)12 << 30) // bytes of queues per scene at most
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1445,6 +1452,7 @@ static int wf_prepare(RtScene* s)
     s->d.stk_spill_t = (float*)s->d_stk_spill;
     s->d.stk_spill = (unsigned short*)((float*)s->d_stk_spill + n_deep);
     s->wf_grid_trace = g_trace, s->wf_grid_any = g_any, s->wf_grid_pipe = g_pipe;
+    s->wf_cus = prop.multiProcessorCount;
     return RT_OK;
 }
 
@@ -1456,7 +1464,22 @@ struct WfPlan {
     int       ns;          // shadow rays per hit and light
 };
 
-static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes, int S)
+static size_t wf_rec_stride(int L, int ns)
+{
+    return (sizeof(WfRecord) + 4 * (size_t)L + (ns > 1 ? 4 * (size_t)((L + 3) / 4) : 0) + 15) & ~(size_t)15;
+}
+
+// Bytes per region: `multi` adds what only the one-launch-per-stage path uses.
+static size_t wf_region_bytes(long long R, int S, int msaa, int L, int ns, bool multi)
+{
+    const size_t rays = 2 * (16 + 16 + 4);
+    const size_t shadow = 2 * (size_t)L * ns * 16 * (ns > 1 ? 2 : 1);
+    const size_t rec = 2 * wf_rec_stride(L, ns);
+    return (size_t)R * (rays + shadow + rec + (multi ? 16 : 0)) + (size_t)S * msaa * (3 * 8 + 4 + 4) +
+           (size_t)S * (multi ? 1 : 8) + 64;
+}
+
+static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int n_pipes, int S, bool multi)
 {
     // rays of one level per camera sample: 1 along mirror chains, up to 2^4 with refraction
     // (levels k = 0..4 spawn, raytracing.cpp:166-168)
@@ -1464,13 +1487,11 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
     const int       L = std::max(P.n_lights, 1);
     const long long R = (long long)S * P.msaa * growth;
     const int       ns = P.soft_n > 0 ? P.soft_n * P.soft_n * P.soft_n : 1;
-    const size_t    per_region = (size_t)R * (2 * (16 + 16 + 8 + 16) + 4 + (size_t)L * (1 + 16 * (size_t)ns * (ns > 1 ? 2 : 1))) +
-                              (size_t)S * P.msaa * (3 * 8 + 4 + 4) + S +
-                              (size_t)(2 + 2 * (1 + L)) * 4;
+    const size_t    per_region = wf_region_bytes(R, S, P.msaa, L, ns, multi);
     size_t budget = WF_WORKSPACE_BUDGET;
     if (s->cfg.budget_mb > 0) budget = (size_t)s->cfg.budget_mb << 20; // tests: force a frame through several chunks
     long long g_max = (long long)(budget / n_pipes / per_region);
-    g_max = std::min<long long>(g_max, (long long)0x7fffffff / R - 1);
+    g_max = std::min<long long>(g_max, (long long)0x7fffffff / (R * L * ns) / 2 - 1);
     g_max = std::max<long long>(g_max, 1);
     const long long g_need = (n_slots + S - 1) / S;
     WfPlan          pl;
@@ -1484,8 +1505,9 @@ static WfPlan wf_plan(const RtScene* s, const DParams& P, long long n_slots, int
 }
 
 #define WF_MAX_PIPES 4
+#define WF_N_BUFFERS 24
 
-static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
+static size_t wf_chunk_bytes(const WfPlan& pl, int L, bool multi, size_t* off)
 {
     const size_t cap = (size_t)pl.G * pl.R, ns = (size_t)pl.n_samples, G = (size_t)pl.G;
     size_t       need = 0;
@@ -1495,57 +1517,56 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, size_t* off)
         ++k;
         need += align256(bytes);
     };
-    for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 8), take(G * 4); // 0..7
-    take(cap * 16 * 2);                        // 8 hits, one set per queue
-    take(cap * 4);                             // 9 wlocal
-    take(cap * 16 * (size_t)L * pl.ns);        // 10 sh_org
-    take(G * 4);                               // 11 sh_cnt
-    take(cap * (size_t)L);                     // 12 occl
-    take((G + 1) * 2 * 4);                     // 13 prefix
-    take(ns * 8 * 3);                          // 14 acc
-    take(ns * 4);                              // 15 s_minT
-    take(ns * 4);                              // 16 s_tri
-    take(sizeof(WfCounters));                  // 17
-    take((size_t)pl.chunk_slots);              // 18 centre flags
-    take(pl.ns > 1 ? cap * 16 * (size_t)L * pl.ns : 0); // 19 sh_dst
+    for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 4), take(G * 4); // 0..7 ray queues
+    take(multi ? cap * 16 : 0);                                   // 8 hits
+    take(2 * cap * 16 * (size_t)L * pl.ns);                       // 9 sh_org
+    take(pl.ns > 1 ? 2 * cap * 16 * (size_t)L * pl.ns : 0);       // 10 sh_dst
+    take(2 * G * 4);                                              // 11 sh_cnt
+    take(2 * cap * wf_rec_stride(L, pl.ns));                      // 12 rec
+    take(multi ? (G + 1) * 2 * 4 : 0);                            // 13 prefix
+    take(multi ? ns * 8 * 3 : 0);                                 // 14 acc
+    take(multi ? 0 : (size_t)pl.chunk_slots * 8);                 // 15 hit_list
+    take(sizeof(WfCounters));                                     // 16
+    take(multi ? (size_t)pl.chunk_slots : 0);                     // 17 centre flags
+    take(ns * 4);                                                 // 18 s_minT
+    take(ns * 4);                                                 // 19 s_tri
     return need;
 }
 
 // Buffers of pipeline `pipe` inside the scene's workspace.
-static void wf_carve(unsigned char* m, const WfPlan& pl, WfBuffers* B, unsigned char** centre_flags,
+static void wf_carve(unsigned char* m, const WfPlan& pl, int L, WfBuffers* B, unsigned char** centre_flags,
                      const size_t* off)
 {
     for (int q = 0; q < 2; ++q) {
         B->rays[q].o_w = (float4*)(m + off[4 * q]);
         B->rays[q].d_ni = (float4*)(m + off[4 * q + 1]);
-        B->rays[q].meta = (uint2*)(m + off[4 * q + 2]);
+        B->rays[q].meta = (unsigned*)(m + off[4 * q + 2]);
         B->rays[q].cnt = (int*)(m + off[4 * q + 3]);
     }
-    for (int q = 0; q < 2; ++q) B->rays[q].hits = (float4*)(m + off[8]) + (size_t)q * pl.G * pl.R;
-    B->wlocal = (float*)(m + off[9]);
-    B->sh_org = (float4*)(m + off[10]);
+    B->hits = (float4*)(m + off[8]);
+    B->sh_org = (float4*)(m + off[9]);
+    B->sh_dst = (float4*)(m + off[10]);
     B->sh_cnt = (int*)(m + off[11]);
-    B->occl = m + off[12];
+    B->rec = m + off[12];
+    B->rec_stride = (int)wf_rec_stride(L, pl.ns);
     B->prefix = (int*)(m + off[13]);
     B->acc = (long long*)(m + off[14]);
-    B->s_minT = (float*)(m + off[15]);
-    B->s_tri = (int*)(m + off[16]);
-    B->ctr = (WfCounters*)(m + off[17]);
-    *centre_flags = m + off[18];
-    B->sh_dst = (float4*)(m + off[19]);
+    B->s_minT = (float*)(m + off[18]);
+    B->s_tri = (int*)(m + off[19]);
+    B->hit_list = (int2*)(m + off[15]);
+    B->ctr = (WfCounters*)(m + off[16]);
+    *centre_flags = m + off[17];
     B->ns = pl.ns;
     B->cap = pl.G * pl.R;
     B->G = pl.G, B->R = pl.R, B->S = pl.S;
     B->n_samples = pl.n_samples;
 }
 
-static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int* head, hipStream_t st)
+static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int msaa, int* head, hipStream_t st)
 {
     const int te = timing_begin(s, K_TRACE_CLOSEST, st);
-    hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d,
-                       (const float4*)C.rays[q].o_w, (const float4*)C.rays[q].d_ni, (const DParams*)nullptr,
-                       (const int*)C.rays[q].cnt, (const int*)C.prefix, 1, C.G, C.R, C.cap, head, C.rays[q].hits,
-                       (unsigned char*)nullptr, s->d_ctr);
+    hipLaunchKernelGGL(k_wf_trace<false>, dim3(s->wf_grid_trace), dim3(WF_BLOCK), s->wf_lds, st, s->d, C,
+                       (const DParams*)s->d_params, q, msaa, head, s->d_ctr);
     timing_end(s, te, st);
 }
 
@@ -1577,12 +1598,27 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     }
     if (s->cfg.region > 0) S = s->cfg.region;
     S = std::max(64, std::min(4096, (S / 64) * 64));
-    if (single) n_pipes = 1;
+    if (single) {
+        n_pipes = 1;
+        S = std::max(32, std::min(S, WF_ACC_SAMPLES / P.msaa / 32 * 32)); // the region's colour sums live in LDS
+    }
+    // blocks the single launch can keep resident with its stacks and colour sums in LDS
+    const size_t lds_single = s->wf_lds + (size_t)S * P.msaa * 24;
+    int          grid_single = s->wf_grid_pipe;
+    if (single) {
+        if (s->wf_single_lds != lds_single) {
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false, false>, WF_BLOCK, lds_single));
+            s->wf_single_grid = std::min(s->wf_grid_pipe, std::max(1, per_cu) * s->wf_cus);
+            s->wf_single_lds = lds_single;
+        }
+        grid_single = s->wf_single_grid;
+    }
     // the single launch keeps one set of buffers per resident block, whatever the size of the frame
-    const long long plan_slots = single ? std::min(n_slots, (long long)s->wf_grid_pipe * S) : (n_slots + n_pipes - 1) / n_pipes;
-    WfPlan pl = wf_plan(s, P, plan_slots, n_pipes, S);
-    size_t off[24];
-    const size_t per_pipe = wf_chunk_bytes(pl, L, off);
+    const long long plan_slots = single ? std::min(n_slots, (long long)grid_single * S) : (n_slots + n_pipes - 1) / n_pipes;
+    WfPlan pl = wf_plan(s, P, plan_slots, n_pipes, S, !single);
+    size_t off[WF_N_BUFFERS];
+    const size_t per_pipe = wf_chunk_bytes(pl, L, !single, off);
     const size_t need = per_pipe * n_pipes;
     if (need > s->wf_mem_bytes) {
         if (s->wf_mem) (void)hipFree(s->wf_mem);
@@ -1604,7 +1640,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     unsigned char* flags[WF_MAX_PIPES];
     for (int k = 0; k < n_pipes; ++k) {
         HIP_TRY(hipStreamWaitEvent(s->wf_stream[k], s->wf_fork, 0));
-        wf_carve((unsigned char*)s->wf_mem + per_pipe * k, pl, &C[k], &flags[k], off);
+        wf_carve((unsigned char*)s->wf_mem + per_pipe * k, pl, L, &C[k], &flags[k], off);
     }
     if (single) {
         hipStream_t st = s->wf_stream[0];
@@ -1613,8 +1649,8 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                                  : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
         WfLaunch A;
         A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
-        A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.centre_hit = flags[0], A.ctr = s->d_ctr;
-        hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), s->wf_lds, st, A); // pl.G <= resident blocks
+        A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.ctr = s->d_ctr;
+        hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), lds_single, st, A); // pl.G <= resident blocks
         HIP_TRY(hipGetLastError());
     }
     for (long long round0 = 0; !single && round0 < n_slots; round0 += pl.chunk_slots * n_pipes) {
@@ -1626,27 +1662,25 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             n[k] = (int)std::max<long long>(0, std::min<long long>(pl.chunk_slots, n_slots - slot0[k]));
             if (n[k] > 0) live = k + 1;
         }
-        WfBuffers V[WF_MAX_PIPES]; // this round's view (ray queues get swapped for MSAA)
+        // level l lives in ray queue l & 1; with MSAA the centre rays pass through queue 1 first
+        const int q0 = P.msaa > 1 ? 1 : 0;
         for (int k = 0; k < live; ++k) {
             hipStream_t st = s->wf_stream[k];
-            V[k] = C[k];
-            HIP_TRY(hipMemsetAsync(V[k].ctr, 0, sizeof(WfCounters), st));
-            HIP_TRY(hipMemsetAsync(V[k].acc, 0, (size_t)pl.n_samples * 8 * 3, st));
-            hipLaunchKernelGGL(k_wf_gen_centre, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], n[k],
+            HIP_TRY(hipMemsetAsync(C[k].ctr, 0, sizeof(WfCounters), st));
+            hipLaunchKernelGGL(k_wf_gen_centre, dim3(C[k].G), dim3(WF_BLOCK), 0, st, P, C[k], q0, slot0[k], n[k],
                                s->d_ctr);
-            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0);
+            hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C[k], q0, 0);
         }
         for (int k = 0; k < live; ++k)
-            wf_launch_trace(s, V[k], 0, &V[k].ctr->head_rays[WF_MAX_DEPTH], s->wf_stream[k]);
+            wf_launch_trace(s, C[k], q0, P.msaa, &C[k].ctr->head_rays[WF_MAX_DEPTH], s->wf_stream[k]);
         HIP_TRY(hipGetLastError());
         bool traced0 = true;
         if (P.msaa > 1) {
             for (int k = 0; k < live; ++k) {
                 hipStream_t st = s->wf_stream[k];
-                hipLaunchKernelGGL(k_wf_msaa_emit, dim3(V[k].G), dim3(WF_BLOCK), 0, st, P, V[k], slot0[k], d_rgb,
+                hipLaunchKernelGGL(k_wf_msaa_emit, dim3(C[k].G), dim3(WF_BLOCK), 0, st, P, C[k], slot0[k], d_rgb,
                                    d_depth, d_tri, flags[k], s->d_ctr);
-                std::swap(V[k].rays[0], V[k].rays[1]);
-                hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, V[k], 0);
+                hipLaunchKernelGGL(k_wf_worklist, dim3(1), dim3(1024), 0, st, C[k], 0, 0);
             }
             traced0 = false;
         }
@@ -1654,30 +1688,27 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             const int q = level & 1;
             for (int k = 0; k < live; ++k) {
                 hipStream_t st = s->wf_stream[k];
-                if (level > 0 || !traced0) wf_launch_trace(s, V[k], q, &V[k].ctr->head_rays[level], st);
-                hipLaunchKernelGGL(k_wf_shade, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level, s->d_ctr);
-                // work lists of the next level's rays (block 0) and of this level's shadow queues
-                hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, V[k], q ^ 1);
+                if (level > 0 || !traced0) wf_launch_trace(s, C[k], q, P.msaa, &C[k].ctr->head_rays[level], st);
+                hipLaunchKernelGGL(k_wf_shade, dim3(C[k].G), dim3(WF_BLOCK), 0, st, s->d, P, C[k], level, slot0[k],
+                                   s->d_ctr);
+                // work lists of the next level's rays (block 0) and of this level's shadow queue
+                hipLaunchKernelGGL(k_wf_worklist, dim3(P.n_lights > 0 ? 2 : 1), dim3(1024), 0, st, C[k], q ^ 1, q);
             }
             for (int k = 0; k < live; ++k) {
                 hipStream_t st = s->wf_stream[k];
                 if (P.n_lights > 0) {
                     const int ta = timing_begin(s, K_TRACE_ANY, st);
-                    hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st,
-                                       s->d, (const float4*)V[k].sh_org, (const float4*)nullptr,
-                                       (const DParams*)s->d_params, (const int*)V[k].sh_cnt,
-                                       (const int*)(V[k].prefix + (V[k].G + 1)), P.n_lights, V[k].G,
-                                       V[k].R, V[k].cap, &V[k].ctr->head_shadow[level][0], (float4*)nullptr,
-                                       V[k].occl, s->d_ctr);
+                    hipLaunchKernelGGL(k_wf_trace<true>, dim3(s->wf_grid_any), dim3(WF_BLOCK), s->wf_lds, st, s->d, C[k],
+                                       (const DParams*)s->d_params, q, P.msaa, &C[k].ctr->head_shadow[level][0],
+                                       s->d_ctr);
                     timing_end(s, ta, st);
                 }
-                hipLaunchKernelGGL(k_wf_resolve, dim3(V[k].G), dim3(WF_BLOCK), 0, st, s->d, P, V[k], level);
             }
             HIP_TRY(hipGetLastError());
         }
         for (int k = 0; k < live; ++k)
             hipLaunchKernelGGL(k_wf_finalize, dim3(blocks_for(n[k], WF_BLOCK)), dim3(WF_BLOCK), 0,
-                               s->wf_stream[k], P, V[k], slot0[k], n[k], (const unsigned char*)flags[k], d_rgb,
+                               s->wf_stream[k], P, C[k], slot0[k], n[k], (const unsigned char*)flags[k], d_rgb,
                                d_depth, d_tri);
         HIP_TRY(hipGetLastError());
     }

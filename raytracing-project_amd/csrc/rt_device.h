@@ -526,17 +526,23 @@ __device__ __forceinline__ void pixel_ray(const PT& P, double x, double y, f3& o
 // tile pixels go by 8x8 blocks so that the 64 lanes of a wave cover a compact
 // screen area.
 template <class PT>
-__device__ __forceinline__ bool slot_to_pixel(const PT& P, long long slot, int& x, int& y)
+__device__ __forceinline__ bool slot_to_pixel(const PT& P, long long slot64, int& x, int& y)
 {
-    const int       tile_px = P.tile_w * P.tile_h;
-    const long long lt = slot / tile_px;
-    const int       within = (int)(slot - lt * tile_px);
-    if (lt >= P.n_my_tiles) return false;
-    const long long gt = (lt / P.span) * P.world + P.rank + lt % P.span;
-    const int       tx = (int)(gt % P.tiles_x), ty = (int)(gt / P.tiles_x);
-    const int       blk = within >> 6, in = within & 63;
-    const int       bpr = P.tile_w >> 3; // 8x8 blocks per tile row
-    x = tx * P.tile_w + (blk % bpr) * 8 + (in & 7);
-    y = ty * P.tile_h + (blk / bpr) * 8 + (in >> 3);
+    // a rank's slots number at most (32768 + 1023)^2 < 2^31: one range check, then 32-bit arithmetic
+    // (64-bit integer division costs some hundred instructions on this hardware)
+    const unsigned tile_px = (unsigned)(P.tile_w * P.tile_h);
+    if (slot64 < 0 || slot64 >= (long long)P.n_my_tiles * tile_px) return false;
+    const unsigned slot = (unsigned)slot64;
+    const unsigned lt = slot / tile_px;
+    const unsigned within = slot - lt * tile_px;
+    const unsigned span = (unsigned)P.span, tiles_x = (unsigned)P.tiles_x;
+    const unsigned round = lt / span;
+    const unsigned gt = round * (unsigned)P.world + (unsigned)P.rank + (lt - round * span);
+    const unsigned ty = gt / tiles_x, tx = gt - ty * tiles_x;
+    const unsigned blk = within >> 6, in = within & 63;
+    const unsigned bpr = (unsigned)P.tile_w >> 3; // 8x8 blocks per tile row
+    const unsigned by = blk / bpr;
+    x = (int)(tx * (unsigned)P.tile_w + (blk - by * bpr) * 8 + (in & 7));
+    y = (int)(ty * (unsigned)P.tile_h + by * 8 + (in >> 3));
     return x < P.W && y < P.H;
 }

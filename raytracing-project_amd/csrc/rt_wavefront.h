@@ -3,29 +3,30 @@
 // The reference shades a camera sample by recursion (raytracing.cpp:61-274):
 // closest hit, one shadow query per light, then up to two child rays, five
 // levels deep.  Here every level of that recursion is one pass over a queue of
-// rays held in HBM:
+// rays.  A ray is traced and shaded by the same lane in one go:
 //
-//   k_wf_trace<false>   closest hit of every ray of the level   -> hit records
-//   k_wf_shade          hit geometry; emits the shadow rays (one queue per
-//                       light) and the child rays of the next level (compacted
-//                       with wave ballots + one atomic per wave); misses add
-//                       the background colour
-//   k_wf_trace<true>    any-hit query per shadow ray             -> occlusion flags
-//   k_wf_resolve        the light loop with the occlusion flags known; adds the
-//                       hit's weighted colour to its camera sample
+//   closest hit  ->  hit geometry, the local colour with every shadow query assumed
+//                    "free", the shadow rays (appended to the level's shadow queue) and
+//                    the child rays (appended to the next level's queue, compacted with
+//                    wave ballots)
 //
-// Queues are cut into regions.  Region r of every queue of a chunk belongs to
-// the same S (128 to 512) pixel slots: their camera rays, then whatever those
-// rays spawn, level after level.  A producer block owns one region, appends
-// into it densely with an LDS counter and publishes the fill count; no global
-// atomic is involved and a region cannot overflow (its size is the largest
-// number of rays its pixels can have in flight).  k_wf_worklist turns the fill
-// counts into a list of 64-ray work items; the two trace kernels are
-// persistent: a fixed grid of waves pulls items off that list with one atomic
-// per 256 rays until it is empty, so no launch depends on a count the host
-// would have to read back.  They keep the KD nodes and the traversal stack in
-// LDS and none of the shading state in registers, which is what gives them the
-// occupancy to hide the latency of the dependent node -> triangle loads.
+// and the shadow rays of level l are traced in the same pass as the closest hits of
+// level l + 1.  A hit whose shadow queries cannot matter is final at once; any other
+// leaves a 36-byte record (colour so far, weight, what each light does to the shadow
+// term) and a count of pending queries.  Every shadow ray reports its answer with one
+// atomic on that count; the ray that brings it to zero has all answers in the returned
+// word and adds the hit's colour to its camera sample.  There is no hit buffer, no
+// second evaluation of the hit geometry and no pass of its own for the light loop.
+//
+// Queues are cut into regions: the S (64 to 512) pixel slots of a region, their camera
+// rays, then whatever those rays spawn, level after level.  A region cannot overflow (its
+// size is the largest number of rays its pixels can have in flight) and appending needs
+// an LDS counter only.  Two drivers exist:
+//   k_wf_pipeline   one persistent launch; a block takes a region and runs all its
+//                   stages, separated by block barriers only (the product path)
+//   k_wf_gen_centre / k_wf_trace / k_wf_msaa_emit / k_wf_shade / k_wf_finalize
+//                   the same per-ray code as one launch per stage over all regions
+//                   (RT_WF_MULTILAUNCH=1: cross-check and single-stage profiling)
 //
 // A camera sample's colour is the sum over its ray tree of (path weight x
 // local colour); the recursion is linear in the child colours
@@ -59,54 +60,79 @@ struct WfCounters {
     int pad;
 };
 
-// Block-local state of the producer stages (LDS).
+// Block-local state of the producer stages (LDS).  Levels rotate through three counters
+// each: a stage reads its inputs' counts, appends with the counters of its outputs and
+// clears those of the stage after it.
 struct WfShared {
-    int child;                  // rays appended to the next level's region
-    int n;                      // rays appended by the camera stages
-    int region;                 // k_wf_pipeline: the region the block works on
-    int sh;                     // shadow rays appended
+    int child[3]; // rays of level l: child[l % 3]
+    int shd[3];   // shadow rays of level l: shd[l % 3]
+    int n_hit;    // k_wf_pipeline, MSAA > 1: pixels whose centre ray hit
+    int n_cam;    // camera rays generated (statistics)
+    int n_closest, n_shadow; // rays traced (statistics; counted per wave here, not in a register per lane)
+    int region;   // k_wf_pipeline: the region the block works on
 };
 
-// One queue of rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
+// One level's rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
+// meta: bits 0-15 the sample (numbered inside the region), 16-18 the level k,
+// 19-26 the route from the camera ray (the soft-shadow generator's key).
 struct WfRays {
-    float4* o_w;  // origin xyz, path weight
-    float4* d_ni; // destination xyz, prev_Ni
-    uint2*  meta; // x: sample index, y: k | shared << 8
-    int*    cnt;  // [G] rays in each region
-    float4* hits; // per ray slot: bits(orig triangle or -1), a, b, t - one set per queue, so the
-                  // closest hits of a level can be traced while the level before is still resolved
+    float4*   o_w;  // origin xyz, path weight
+    float4*   d_ni; // destination xyz, prev_Ni
+    unsigned* meta;
+    int*      cnt;  // [G] rays in each region
 };
 
+__device__ __forceinline__ unsigned wf_meta(unsigned sample, unsigned k, unsigned route)
+{
+    return sample | (k << 16) | ((route & 0xffu) << 19);
+}
+
+// Record of a hit that waits for shadow answers; `rec_stride` bytes apart.  After it: per light
+// the value the light's angle sets shadowMax to before its query (-1 = leaves it), then, with
+// soft shadows, per light the number of occluded samples (one byte each).
+struct WfRecord {
+    float    cr, cg, cb; // colour with all lights unoccluded, before the shadow term
+    float    wl;         // weight of that colour in its camera sample
+    unsigned sample;     // of the region
+    unsigned pending;    // bits 0-7 queries still out, 8-31 lights 0-23 found occluded; soft shadows: queries only
+    unsigned occ_hi[2];  // lights 24-87 found occluded
+};
+
+// Buffers that exist once per level parity lie back to back: parity 1 starts one stride
+// (the size named in the comment) after parity 0.
 struct WfBuffers {
-    WfRays         rays[2];   // ping-pong between levels
-    float*         wlocal;    // per ray slot: weight of the hit's own colour (0 for a miss)
-    float4*        sh_org;    // [cap * lights * ns]: shadow ray origin xyz, bits(light << 24 | ray slot in its region);
-                              // one queue per region for all lights, R * lights * ns entries each
-    float4*        sh_dst;    // [cap * lights * ns]: soft shadows only, the sample's destination
-    int*           sh_cnt;    // [G]
-    unsigned char* occl;      // [light][cap]: 1 = occluded (soft shadows: occluded samples), indexed by ray slot
-    int*           prefix;    // [G + 1] for the ray queue, then [G + 1] for the shadow queue
-    long long*     acc;       // [3][n_samples] fixed-point colour sums
+    WfRays         rays[2];   // level l in rays[l & 1]
+    float4*        hits;      // [cap] multi-launch path only: bits(triangle or -1), a, b, t
+    float4*        sh_org;    // x2 [cap * lights * ns]: shadow ray origin xyz, bits(light << 24 | ray slot in
+                              // its region); one queue per region for all lights
+    float4*        sh_dst;    // x2 [cap * lights * ns]: soft shadows only, the sample's destination
+    int*           sh_cnt;    // x2 [G]
+    unsigned char* rec;       // x2 [cap * rec_stride]: per ray slot, the record of a hit that waits for shadow
+                              // answers (WfRecord, then one float per light, then the soft-shadow counts)
+    int*           prefix;    // multi-launch: [G + 1] for the ray queue, then [G + 1] for the shadow queue
+    long long*     acc;       // [3][n_samples] fixed-point colour sums; the single launch keeps them in LDS instead
     float*         s_minT;    // per sample: t of the camera ray's hit (FLT_MAX = miss)
     int*           s_tri;     // per sample: triangle of the camera ray's hit
+    int2*          hit_list;  // k_wf_pipeline, MSAA > 1: [G * S] pixel slots whose centre ray hit: slot, x | y << 16
     WfCounters*    ctr;
     int            cap;       // slots of every queue = G * R
     int            G, R;      // regions, ray slots per region
     int            S;         // pixel slots per region
-    int            n_samples; // samples of a chunk (upper bound)
+    int            n_samples; // samples the buffers hold = G * S * msaa
     int            ns;        // shadow rays per hit and light: 1, or soft_n^3 with soft shadows
+    int            rec_stride; // bytes per record: sizeof(WfRecord) + 4 * lights (+ 4 * ceil(lights / 4)), in 16s
 };
 
 // ---------------------------------------------------------------------------
 // work lists and the persistent trace kernels
 // ---------------------------------------------------------------------------
 // Work-item prefix sums: item counts ceil(cnt / 64) per region, exclusive scan.
-// Block 0: the G regions of ray queue `q`.  Block 1: the G regions of the shadow queue.
-__global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q)
+// Block 0: the G regions of ray queue `q`.  Block 1: the G regions of the shadow queue of parity `par`.
+__global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int par)
 {
     __shared__ int s_part[1024];
     const int      n = B.G;
-    const int*     cnt = blockIdx.x == 0 ? B.rays[q].cnt : B.sh_cnt;
+    const int*     cnt = blockIdx.x == 0 ? B.rays[q].cnt : B.sh_cnt + (size_t)par * B.G;
     int*           out = blockIdx.x == 0 ? B.prefix : B.prefix + (B.G + 1);
     const int      per = (n + 1023) / 1024;
     const int      lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
@@ -272,30 +298,442 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
     return best_orig >= 0;
 }
 
+// ---------------------------------------------------------------------------
+// queue helpers
+// ---------------------------------------------------------------------------
+// Positions inside the block's own region: `per` consecutive slots for every
+// lane with mine == true; one LDS atomic per wave.
+__device__ __forceinline__ int wf_append(int* lds_counter, bool mine, int per = 1)
+{
+    const unsigned long long m = __ballot(mine);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int       base = 0;
+    if (lane == leader) base = atomicAdd(lds_counter, __popcll(m) * per);
+    base = __shfl(base, leader);
+    return mine ? base + __popcll(m & ((1ull << lane) - 1ull)) * per : -1;
+}
+
+__device__ __forceinline__ long long wf_fix(float v) { return (long long)llrint((double)v * WF_FIX_SCALE); }
+
+// Where the colour sums of the region being worked on are: three planes of `n` 64-bit sums,
+// `at[sample]` the first.  The single launch keeps them in LDS (a region belongs to one block, and
+// an atomic on HBM is a transaction with the memory fabric: with the sums in HBM they made up a
+// fifth of the launch's traffic); the multi-launch kernels in the workspace.
+typedef __attribute__((address_space(3))) long long* WfLdsSums; // typed as LDS: ds_add_u64, not a flat atomic
+template <class PTR>
+struct WfAccT {
+    PTR      at;
+    unsigned n;
+};
+typedef WfAccT<long long*> WfAcc;   // in the workspace
+typedef WfAccT<WfLdsSums>  WfAccL;  // in LDS
+
+// Several rays of a sample may finish at the same time: order-free integer adds.
+template <class ACC>
+__device__ __forceinline__ void wf_acc_add(const ACC& a, unsigned sample, f3 c)
+{
+    __hip_atomic_fetch_add(a.at + sample, wf_fix(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.at + a.n + sample, wf_fix(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.at + 2 * a.n + sample, wf_fix(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The camera ray is the first to touch its sample's sums: it sets them.
+template <class ACC>
+__device__ __forceinline__ void wf_acc_set(const ACC& a, unsigned sample, f3 c)
+{
+    a.at[sample] = wf_fix(c.x);
+    a.at[a.n + sample] = wf_fix(c.y);
+    a.at[2 * a.n + sample] = wf_fix(c.z);
+}
+
+// Hit geometry: raytracing.cpp:76-108.
+struct WfSurf {
+    f3    hp, N, viewDir;
+    f3    Kd, Ks;
+    float Ns, Ni;
+    int   illum, has_Ni, tex;
+    int4  info;
+};
+
+__device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dir, int orig, float a, float b, float t,
+                                           WfSurf& s)
+{
+    s.hp = o + dir * t; // raytracing.cpp:384
+    const float4 s0 = S.tri_shade[3 * orig], s1 = S.tri_shade[3 * orig + 1], s2 = S.tri_shade[3 * orig + 2];
+    s.info = S.tri_info[orig];
+    const float4 m0 = S.mats[4 * s.info.x], m1 = S.mats[4 * s.info.x + 1], m2 = S.mats[4 * s.info.x + 2];
+    s.Kd = mk3(m0.x, m0.y, m0.z), s.Ks = mk3(m1.x, m1.y, m1.z);
+    s.Ns = m0.w, s.Ni = m1.w;
+    s.illum = __float_as_int(m2.x), s.has_Ni = __float_as_int(m2.y), s.tex = __float_as_int(m2.z);
+    const float u = a, v = b, w = 1.0f - u - v;
+    s.N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
+    normalize3(s.N);
+    s.viewDir = o - s.hp;
+    normalize3(s.viewDir);
+}
+
+// Where the data of the region being worked on lie, and the counters its stage appends with.
+template <class ACC>
+struct WfRegion {
+    size_t    base;      // first ray slot of the region in every queue: region * R
+    size_t    sample0;   // first sample of the region in s_minT / s_tri: region * S * msaa
+    ACC       acc;       // the colour sums, and
+    unsigned  acc0;      // the region's first sample in them
+    long long slot_base; // pixel slot of the region's first pixel slot
+    int       par;       // parity of the level being shaded (its shadow queue and records)
+    int*      n_child;   // rays appended to the next level's queue
+    int*      n_sh;      // shadow rays appended
+};
+
+// ---------------------------------------------------------------------------
+// one ray after its closest-hit walk: raytracing.cpp:70-271 without the recursion
+// ---------------------------------------------------------------------------
+// Called by all lanes of a wave together (the appends ballot); `valid` says whether the lane
+// holds a ray.  j: the ray's slot in its region's queue.
+//
+// The light loop of raytracing.cpp:110-164 is evaluated with every shadow query taken as
+// "free"; what an occluded light changes is the shadow term alone.  That term is kept apart:
+// the colour is C - shadowPart * (sum over the lights of shadowMax), C = ambient or texture +
+// diffuse + specular of all lights (the reference subtracts light by light between the
+// additions: same value up to the last bits of a float).  shadowMax is carried from light to
+// light (raytracing.cpp:104); per light the hit records v = the value the light's angle sets
+// it to before its query, or -1 if the angle leaves it alone.
+template <bool SOFT, class PT, class ACC>
+__device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const WfBuffers& B, const WfRays out,
+                                             const WfRegion<ACC>& g, bool valid, int j, f3 o, f3 dir, float w,
+                                             float prev_ni, unsigned meta, bool got, int orig, float ha, float hb,
+                                             float ht, unsigned& n_shaded, unsigned& n_child)
+{
+    const int      L = P.n_lights;
+    const unsigned sl = meta & 0xffffu;
+    const int      k = (int)((meta >> 16) & 7u);
+    const unsigned route = (meta >> 19) & 0xffu;
+    const size_t   sample = g.sample0 + sl;
+    unsigned char* rec = B.rec + ((size_t)g.par * B.cap + g.base + j) * B.rec_stride;
+    float*         rec_v = (float*)(rec + sizeof(WfRecord));
+    const int      per = SOFT ? B.ns : 1;
+    const size_t   sq0 = ((size_t)g.par * B.cap + g.base) * L * per; // the region's shadow queue
+    const bool is_hit = valid && got;
+    bool       final_now = valid && !got;
+    f3         colour = mk3(0, 0, 0);
+    if (final_now) colour = mk3(P.bg[0], P.bg[1], P.bg[2]) * w; // raytracing.cpp:74
+    WfSurf s;
+    f3     C = mk3(0, 0, 0);
+    if (is_hit) {
+        wf_surface(S, o, dir, orig, ha, hb, ht, s), ++n_shaded;
+        if (s.tex < 0) C = s.Kd * P.backgroundlighting; // raytracing.cpp:92-95
+        else C = sample_texture(S, s.tex, s.info, s.hp);
+    }
+    // ---- children first, raytracing.cpp:166-271 (their registers are free again before the light
+    // loop starts): A = mirror or transmitted ray, B = reflected ray of a refracting surface ----
+    float wl = 0.0f;
+    {
+        bool     hasA = false, hasB = false;
+        f3       a_o = mk3(0, 0, 0), a_d = mk3(0, 0, 0), b_o = mk3(0, 0, 0), b_d = mk3(0, 0, 0);
+        float    a_w = 0.0f, b_w = 0.0f, n2 = 1.0f;
+        unsigned a_kind = 0; // 1 mirror, 2 transmitted, 3 reflected (the soft-shadow generator's key)
+        if (is_hit) {
+            wl = w;
+            if (k + 1 < 5) {
+                const float n1 = (prev_ni != 0.0f) ? prev_ni : 1.0f;
+                n2 = s.has_Ni ? s.Ni : 1.0f;
+                if (s.illum == 3) {
+                    const f3 refl = dir - s.N * (2.0f * dot3(s.N, dir));
+                    wl = 0.5f * w;
+                    a_o = s.hp + refl * 0.001f, a_d = s.hp + refl, a_w = 0.5f * w, a_kind = 1, hasA = true;
+                } else if (s.Ni > 1.0f) {
+                    f3 I = dir;
+                    normalize3(I);
+                    const float eta = (n1 != n2) ? n2 : __fdiv_rn(1.0f, n2);
+                    const float cosI = dot3(I, s.N);
+                    const float sin2T = (float)(((double)eta * (double)eta) * (1.0 - ((double)cosI * (double)cosI)));
+                    float       rf = sin2T;
+                    rf = rf < 0.0f ? 0.0f : rf;
+                    rf = rf > 1.0f ? 1.0f : rf;
+                    float wLocal = 0.5f * rf;
+                    if (sin2T <= 1.0f) {
+                        const float f = (float)((double)(eta * cosI) - sqrt((double)(1.0f - sin2T)));
+                        const f3    tRay = I * eta + s.N * f;
+                        wLocal += 0.1f * (1.0f - rf);
+                        const float wT = 0.9f * (1.0f - rf) * w;
+                        if (wT != 0.0f) a_o = s.hp + tRay * 0.001f, a_d = s.hp + tRay, a_w = wT, a_kind = 2, hasA = true;
+                    }
+                    const float wR = 0.5f * rf * w;
+                    if (wR != 0.0f) {
+                        const f3 refRay = I - s.N * (2.0f * dot3(I, s.N));
+                        b_o = s.hp + refRay * 0.001f, b_d = s.hp + refRay, b_w = wR, hasB = true;
+                    }
+                    wl = wLocal * w;
+                }
+            }
+        }
+        n_child += (hasA ? 1u : 0u) + (hasB ? 1u : 0u);
+        int pos = wf_append(g.n_child, hasA);
+        if (hasA && pos < B.R) { // cannot exceed R by construction; the guard keeps a bug from writing outside
+            const size_t p = g.base + pos;
+            out.o_w[p] = make_float4(a_o.x, a_o.y, a_o.z, a_w);
+            out.d_ni[p] = make_float4(a_d.x, a_d.y, a_d.z, n2);
+            out.meta[p] = wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | a_kind : 0u);
+        }
+        pos = wf_append(g.n_child, hasB);
+        if (hasB && pos < B.R) {
+            const size_t p = g.base + pos;
+            out.o_w[p] = make_float4(b_o.x, b_o.y, b_o.z, b_w);
+            out.d_ni[p] = make_float4(b_d.x, b_d.y, b_d.z, n2);
+            out.meta[p] = wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | 3u : 0u);
+        }
+    }
+    // ---- the light loop ----
+    float              shadowMax = 0.0f, T = 0.0f;
+    int                ncast = 0;
+    unsigned long long soft_id = 0;
+    if (SOFT && is_hit) {
+        const int msaa = P.msaa;
+        const int slot = msaa == 1 ? (int)sl : (int)(sl / (unsigned)msaa);
+        const int sn = msaa == 1 ? 0 : (int)(sl % (unsigned)msaa) + 1;
+        int       px = 0, py = 0;
+        slot_to_pixel(P, g.slot_base + slot, px, py);
+        soft_id = ((unsigned long long)py * P.W + px) * 32 + sn;
+    }
+    for (int li = 0; li < L; ++li) {
+        bool cast = false;
+        f3   lightDir = mk3(0, 0, 0);
+        if (is_hit) {
+            lightDir = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]) - s.hp;
+            normalize3(lightDir);
+            float angle = dot3(s.N, lightDir);
+            if (angle > 0.0f) C = C + (s.Kd * angle) * P.diffusePower;
+            angle = dot3(lightDir, s.N);
+            float v = -1.0f;
+            if (angle <= 0.2f) v = 1.0f;
+            else if (angle < 0.5f) {
+                angle -= 0.2f;
+                v = 3.33f * (0.3f - angle);
+                v = v < 0.0f ? 0.0f : v; // the std::max(shadowMax, softShadow) with softShadow >= 0 that follows
+            }
+            if (v >= 0.0f) shadowMax = v;
+            if (angle > 0.0f) {
+                f3 halfway = lightDir + s.viewDir;
+                normalize3(halfway);
+                const float ah = dot3(s.N, halfway);
+                if (ah > 0.0f) C = C + s.Ks * powf(ah, s.Ns);
+                // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
+                // shadowMax is its value with every query so far answered "free"; if that is 1
+                // already - set by a grazing angle at this light, or carried from an earlier one -
+                // the answer cannot change the colour and the query is not traced.  (Soft shadows
+                // take the maximum with a sum that rounding may carry past 1: all of them are traced.)
+                cast = SOFT || shadowMax != 1.0f;
+            }
+            T += shadowMax;
+            rec_v[li] = v;
+        }
+        // one queue for all lights: a wave of shadow rays is full whatever the share of each light
+        const int pos = wf_append(g.n_sh, cast, per);
+        if (cast) {
+            ++ncast;
+            const f3  so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
+            const int tag = (li << 24) | j;
+            if (!SOFT) {
+                B.sh_org[sq0 + pos] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
+            } else { // raytracing.cpp:145-160: ns rays towards jittered points around the light
+                for (int si = 0; si < per; ++si) {
+                    float4 dd = make_float4(0, 0, 0, 0);
+                    soft_dest(&P.lights[0], &P.soft_x[0], P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si,
+                              soft_id, route, dd.x, dd.y, dd.z);
+                    B.sh_org[sq0 + pos + si] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
+                    B.sh_dst[sq0 + pos + si] = dd;
+                }
+            }
+        }
+    }
+    if (is_hit) {
+        if (ncast == 0) { // no answer can change it: final
+            const float sm = T * __fdiv_rn(P.ShadowFactor, (float)L); // raytracing.cpp:102
+            colour = (C - mk3(sm, sm, sm)) * wl;
+            final_now = true;
+        } else {
+            *(float4*)rec = make_float4(C.x, C.y, C.z, wl);
+            *(uint4*)(rec + 16) = make_uint4(sl, (unsigned)(ncast * per), 0u, 0u);
+            if (SOFT) {
+                unsigned* rec_n = (unsigned*)(rec_v + L);
+                for (int x = 0; x < ((L + 3) >> 2); ++x) rec_n[x] = 0u;
+            }
+        }
+    }
+    if (valid) {
+        if (k == 0) { // the camera ray fixes the sample's depth and triangle
+            B.s_minT[sample] = ht;
+            B.s_tri[sample] = got ? orig : -1;
+            wf_acc_set(g.acc, g.acc0 + sl, final_now ? colour : mk3(0, 0, 0));
+        } else if (final_now) wf_acc_add(g.acc, g.acc0 + sl, colour);
+    }
+}
+
+// A word that other lanes change with atomics, read past the vector L1.
+__device__ __forceinline__ unsigned wf_peek(const unsigned* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A shadow ray reports its answer.  The ray that brings the hit's count of pending queries to
+// zero knows every answer and finishes the light loop: raytracing.cpp:142-164 with the
+// queries answered.  rec: the hit's record; sample0: first sample of the hit's region.
+template <bool SOFT, class PT, class ACC>
+__device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, size_t slot, const ACC& acc,
+                                               unsigned acc0, int li, bool occluded)
+{
+    const int      L = P.n_lights;
+    unsigned char* rec = B.rec + slot * B.rec_stride;
+    WfRecord*      R = (WfRecord*)rec;
+    const float*   rec_v = (const float*)(rec + sizeof(WfRecord));
+    unsigned*      rec_n = (unsigned*)(rec_v + L);
+    unsigned       bits = 0;
+    if (!SOFT) {
+        unsigned delta = 0xffffffffu; // one query less pending
+        if (occluded) {
+            if (li < 24) delta += 1u << (8 + li);
+            else {
+                atomicOr(&R->occ_hi[(li - 24) >> 5], 1u << ((li - 24) & 31));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // performed before the count drops
+            }
+        }
+        const unsigned old = atomicAdd(&R->pending, delta);
+        if ((old & 0xffu) != 1u) return;
+        bits = (old + delta) >> 8;
+    } else {
+        if (occluded) { // count in the light's byte (at most 216 samples): add into its 32-bit word
+            atomicAdd(&rec_n[li >> 2], 1u << (8 * (unsigned)(li & 3)));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (atomicSub(&R->pending, 1u) != 1u) return;
+    }
+    const float4 c = *(const float4*)rec;
+    const unsigned sample = acc0 + R->sample;
+    float        shadowMax = 0.0f, T = 0.0f;
+    for (int l2 = 0; l2 < L; ++l2) {
+        const float v = rec_v[l2];
+        if (v >= 0.0f) shadowMax = v;
+        if (!SOFT) {
+            const unsigned occ = l2 < 24 ? (bits >> l2) & 1u : (wf_peek(&R->occ_hi[(l2 - 24) >> 5]) >> ((l2 - 24) & 31)) & 1u;
+            if (occ) shadowMax = 1.0f;
+        } else { // raytracing.cpp:155-157: one float addition per occluded sample
+            const unsigned n_occ = (wf_peek(&rec_n[l2 >> 2]) >> (8 * (unsigned)(l2 & 3))) & 0xffu;
+            float          softShadow = 0.0f;
+            for (unsigned x = 0; x < n_occ; ++x) softShadow += P.soft_w;
+            shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax;
+        }
+        T += shadowMax;
+    }
+    const float sm = T * __fdiv_rn(P.ShadowFactor, (float)L);
+    wf_acc_add(acc, sample, (mk3(c.x, c.y, c.z) - mk3(sm, sm, sm)) * c.w);
+}
+
+// Pixels from sample sums.  MSAA == 1: one sample per slot.  MSAA > 1: ordered float sum of
+// the samples / msaa, depth = mean of minT over the samples that hit (main.cpp:449-507);
+// the caller passes only pixels whose centre ray hit.
+template <class PT, class ACC>
+__device__ __forceinline__ void wf_finalize_pixel(const PT& P, const WfBuffers& B, const ACC& acc, unsigned acc_i,
+                                                  size_t p, size_t sample, float* rgb, float* depth, int* tri)
+{
+    if (P.msaa == 1) {
+        rgb[3 * p] = wf_clamp01((float)((double)acc.at[acc_i] / WF_FIX_SCALE));
+        rgb[3 * p + 1] = wf_clamp01((float)((double)acc.at[acc.n + acc_i] / WF_FIX_SCALE));
+        rgb[3 * p + 2] = wf_clamp01((float)((double)acc.at[2 * acc.n + acc_i] / WF_FIX_SCALE));
+        depth[p] = B.s_minT[sample];
+        if (tri) tri[p] = B.s_tri[sample];
+        return;
+    }
+    float r = 0, g = 0, b = 0, dsum = 0;
+    int   hits = 0;
+    for (int s = 0; s < P.msaa; ++s) {
+        const float sr = (float)((double)acc.at[acc_i + s] / WF_FIX_SCALE);
+        const float sg = (float)((double)acc.at[acc.n + acc_i + s] / WF_FIX_SCALE);
+        const float sb = (float)((double)acc.at[2 * acc.n + acc_i + s] / WF_FIX_SCALE);
+        if (s == 0) r = sr, g = sg, b = sb;
+        else r += sr, g += sg, b += sb;
+        const float mt = B.s_minT[sample + s];
+        if (mt != RT_FLT_MAX) dsum += mt, ++hits;
+    }
+    const float nn = (float)P.msaa;
+    rgb[3 * p] = wf_clamp01(__fdiv_rn(r, nn));
+    rgb[3 * p + 1] = wf_clamp01(__fdiv_rn(g, nn));
+    rgb[3 * p + 2] = wf_clamp01(__fdiv_rn(b, nn));
+    depth[p] = hits > 0 ? __fdiv_rn(dsum, (float)hits) : RT_FLT_MAX;
+}
+
+// The pixel of a centre ray that missed (main.cpp:439-445).
+template <class PT>
+__device__ __forceinline__ void wf_background_pixel(const PT& P, size_t p, float* rgb, float* depth)
+{
+    rgb[3 * p] = wf_clamp01(P.bg[0]);
+    rgb[3 * p + 1] = wf_clamp01(P.bg[1]);
+    rgb[3 * p + 2] = wf_clamp01(P.bg[2]);
+    depth[p] = RT_FLT_MAX;
+}
+
+// ---------------------------------------------------------------------------
+// one launch per stage (RT_WF_MULTILAUNCH=1)
+// ---------------------------------------------------------------------------
+// Block r: centre rays of pixel slots slot0 + [r * S, (r + 1) * S) that lie inside the
+// frame, appended to region r of queue `q`.  meta: the slot inside the region.
+__global__ void __launch_bounds__(WF_BLOCK)
+k_wf_gen_centre(DParams P, WfBuffers B, int q, long long slot0, int n, DCounters* ctr)
+{
+    __shared__ int s_n;
+    const int      r = blockIdx.x;
+    const WfRays   out = B.rays[q];
+    const size_t   base = (size_t)r * B.R;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int s_pad = (B.S + 63) & ~63;
+    for (int j = threadIdx.x; j < s_pad; j += WF_BLOCK) {
+        const int  i = j < B.S ? r * B.S + j : n;
+        int        x = 0, y = 0;
+        const bool valid = i < n && slot_to_pixel(P, slot0 + i, x, y);
+        const int  pos = wf_append(&s_n, valid);
+        if (valid) {
+            f3 o, d;
+            pixel_ray(P, (double)x, (double)y, o, d);
+            out.o_w[base + pos] = make_float4(o.x, o.y, o.z, 1.0f);
+            out.d_ni[base + pos] = make_float4(d.x, d.y, d.z, 1.0f); // prev_Ni = 1.0f (main.cpp:528)
+            out.meta[base + pos] = wf_meta((unsigned)j, 0u, 0u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out.cnt[r] = s_n;
+        atomicAdd(&ctr->camera_rays, (unsigned long long)s_n);
+    }
+}
+
 // Persistent trace kernel: a fixed grid of waves pulls 64-ray work items off the list
 // (WF_ITEMS_PER_FETCH per atomic) until it is empty.  The 64 lanes of a wave start
 // their rays together: neighbouring rays visit the same nodes and leaves at the same
 // time, so most of a wave's loads fall into a few cache lines.  (Refilling single lanes
 // as their rays finish was measured: it keeps more lanes busy but scatters the lanes
 // over the tree, and the extra cache lines per load cost more than the idle lanes.)
-//   ANY = false: queue of a level -> hit records.
-//   ANY = true : shadow queue of a level (regions of R * n_lights slots); every ray ends at
-//                the light its record names -> occlusion bytes.
+//   ANY = false: queue `q` -> hit records.
+//   ANY = true : shadow queue of parity `q` (regions of R * n_lights slots); every ray ends at
+//                the light its record names and reports to its hit's record.
 // LDS: per-thread stacks of ushort node indices.  (Keeping the top of the node array in
 // LDS too was measured: 27.7 ms per 4K frame without it, 29.9 / 32.5 / 39.5 ms with 32 / 48 /
 // 64 KB per block - the nodes stay in the vector L1 and the LDS costs occupancy.)
 template <bool ANY>
 __global__ void __launch_bounds__(WF_BLOCK)
-k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ d_ni, DParams const* lights,
-           const int* __restrict__ cnt, const int* __restrict__ prefix, int n_lights, int n_regions, int R, int cap,
-           int* head, float4* hits, unsigned char* occl, DCounters* ctr)
+k_wf_trace(DScene S, WfBuffers B, const DParams* __restrict__ Pp, int q, int msaa, int* head, DCounters* ctr)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
-    const WfStack   stk = wf_stack(S, s_mem);
-    const int       total = prefix[n_regions];
-    const int       lane = threadIdx.x & 63;
-    unsigned        n_tests = 0, n_nodes = 0, n_rays = 0;
-    int             r = 0; // region of the previous item: consecutive items mostly share it
+    const WfStack stk = wf_stack(S, s_mem);
+    const int*    prefix = ANY ? B.prefix + (B.G + 1) : B.prefix;
+    const int*    cnt = ANY ? B.sh_cnt + (size_t)q * B.G : B.rays[q].cnt;
+    const int     n_regions = B.G;
+    const int     total = prefix[n_regions];
+    const int     lane = threadIdx.x & 63;
+    const int     L = ANY ? Pp->n_lights : 1;
+    unsigned      n_tests = 0, n_nodes = 0, n_rays = 0;
+    int           r = 0; // region of the previous item: consecutive items mostly share it
     // several items per atomic while there is plenty of work, single items when the
     // list is short compared with the waves in flight (keeps the tail of the launch short)
     const int per_fetch = total >= 8 * (int)gridDim.x * (WF_BLOCK / 64) ? WF_ITEMS_PER_FETCH : 1;
@@ -317,21 +755,25 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
             }
             const int idx = (t - prefix[r]) * 64 + lane;
             if (idx >= cnt[r]) continue;
-            const size_t i = (size_t)r * R * (ANY ? n_lights : 1) + idx;
-            const float4 ow = o_w[i];
-            const f3     o = mk3(ow.x, ow.y, ow.z);
-            const int    li = ANY ? (int)((unsigned)__float_as_int(ow.w) >> 24) : 0;
-            f3           dst;
-            if (ANY) dst = mk3(lights->lights[3 * li], lights->lights[3 * li + 1], lights->lights[3 * li + 2]);
-            else {
-                const float4 dn = d_ni[i];
-                dst = mk3(dn.x, dn.y, dn.z);
-            }
             HitRec h;
             ++n_rays;
-            const bool got = wf_traverse<ANY>(S, stk, o, dst - o, h, n_tests, n_nodes);
-            if (ANY) occl[(size_t)li * cap + (size_t)r * R + (__float_as_int(ow.w) & 0xffffff)] = got ? 1 : 0;
-            else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
+            if (!ANY) {
+                const size_t i = (size_t)r * B.R + idx;
+                const float4 ow = B.rays[q].o_w[i], dn = B.rays[q].d_ni[i];
+                const f3     o = mk3(ow.x, ow.y, ow.z);
+                const bool   got = wf_traverse<false>(S, stk, o, mk3(dn.x, dn.y, dn.z) - o, h, n_tests, n_nodes);
+                B.hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
+            } else {
+                const size_t i = ((size_t)q * B.cap + (size_t)r * B.R) * L + idx;
+                const float4 ow = B.sh_org[i];
+                const f3     o = mk3(ow.x, ow.y, ow.z);
+                const int    li = (int)((unsigned)__float_as_int(ow.w) >> 24);
+                const f3     dst = mk3(Pp->lights[3 * li], Pp->lights[3 * li + 1], Pp->lights[3 * li + 2]);
+                const bool   got = wf_traverse<true>(S, stk, o, dst - o, h, n_tests, n_nodes);
+                const WfAcc acc = {B.acc, (unsigned)B.n_samples};
+                wf_shadow_done<false>(*Pp, B, (size_t)q * B.cap + (size_t)r * B.R + (__float_as_int(ow.w) & 0xffffff), acc,
+                                      (unsigned)(r * B.S * msaa), li, got);
+            }
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
@@ -346,366 +788,17 @@ k_wf_trace(DScene S, const float4* __restrict__ o_w, const float4* __restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------
-// queue helpers
-// ---------------------------------------------------------------------------
-// Positions inside the block's own region: `per` consecutive slots for every
-// lane with mine == true; one LDS atomic per wave.
-__device__ __forceinline__ int wf_append(int* lds_counter, bool mine, int per = 1)
-{
-    const unsigned long long m = __ballot(mine);
-    if (m == 0) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int       base = 0;
-    if (lane == leader) base = atomicAdd(lds_counter, __popcll(m) * per);
-    base = __shfl(base, leader);
-    return mine ? base + __popcll(m & ((1ull << lane) - 1ull)) * per : -1;
-}
-
-__device__ __forceinline__ void wf_acc_add(const WfBuffers& B, unsigned sample, f3 c, bool shared)
-{
-    const long long r = (long long)llrint((double)c.x * WF_FIX_SCALE);
-    const long long g = (long long)llrint((double)c.y * WF_FIX_SCALE);
-    const long long b = (long long)llrint((double)c.z * WF_FIX_SCALE);
-    long long*      pr = B.acc + sample;
-    long long*      pg = B.acc + (size_t)B.n_samples + sample;
-    long long*      pb = B.acc + 2 * (size_t)B.n_samples + sample;
-    if (shared) { // several rays of this sample may be in the level: order-free integer adds
-        atomicAdd((unsigned long long*)pr, (unsigned long long)r);
-        atomicAdd((unsigned long long*)pg, (unsigned long long)g);
-        atomicAdd((unsigned long long*)pb, (unsigned long long)b);
-    } else { // the only ray of its sample in this level
-        *pr += r;
-        *pg += g;
-        *pb += b;
-    }
-}
-
-// Hit geometry shared by k_wf_shade and k_wf_resolve: raytracing.cpp:76-108.
-struct WfSurf {
-    f3    hp, N, viewDir, dir;
-    f3    Kd, Ks;
-    float Ns, Ni;
-    int   illum, has_Ni, tex;
-    int4  info;
-};
-
-__device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dst, float4 hit, WfSurf& s)
-{
-    const int orig = __float_as_int(hit.x);
-    s.dir = dst - o;
-    s.hp = o + s.dir * hit.w; // raytracing.cpp:384
-    const float4 s0 = S.tri_shade[3 * orig], s1 = S.tri_shade[3 * orig + 1], s2 = S.tri_shade[3 * orig + 2];
-    s.info = S.tri_info[orig];
-    const float4 m0 = S.mats[4 * s.info.x], m1 = S.mats[4 * s.info.x + 1], m2 = S.mats[4 * s.info.x + 2];
-    s.Kd = mk3(m0.x, m0.y, m0.z), s.Ks = mk3(m1.x, m1.y, m1.z);
-    s.Ns = m0.w, s.Ni = m1.w;
-    s.illum = __float_as_int(m2.x), s.has_Ni = __float_as_int(m2.y), s.tex = __float_as_int(m2.z);
-    const float u = hit.y, v = hit.z, w = 1.0f - u - v;
-    s.N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
-    normalize3(s.N);
-    s.viewDir = o - s.hp;
-    normalize3(s.viewDir);
-}
-
-// Per-light terms of raytracing.cpp:110-143 up to the shadow query: returns
-// whether a shadow ray is cast and the self-shadow value set before it.
-__device__ __forceinline__ bool wf_light_setup(const WfSurf& s, f3 lpos, f3& lightDir, float& angle,
-                                               float& shadowMax)
-{
-    lightDir = lpos - s.hp;
-    normalize3(lightDir);
-    angle = dot3(lightDir, s.N);
-    if (angle <= 0.2f) shadowMax = 1.0f;
-    else if (angle < 0.5f) {
-        angle -= 0.2f;
-        shadowMax = 3.33f * (0.3f - angle);
-    }
-    return angle > 0.0f;
-}
-
-// ---------------------------------------------------------------------------
-// shade: one block per region, one thread per ray of level `level`
-// ---------------------------------------------------------------------------
-template <bool SOFT = false, class ST = DScene, class PT = DParams>
-__device__ __forceinline__ void wf_shade_region(const ST& S_, const PT& P, const WfBuffers& B,
-                                                const WfRays in, const WfRays out, int r, WfShared* sh,
-                                                unsigned& n_shaded, unsigned& n_child, long long slot0 = 0)
-{
-    const DScene S = wf_scene(S_);
-    int&         s_child = sh->child;
-    int&         s_sh = sh->sh;
-    const int    n = in.cnt[r];
-    const size_t base = (size_t)r * B.R;
-    const size_t sbase = base * P.n_lights * (SOFT ? B.ns : 1); // the region's shadow queue
-    if (threadIdx.x == 0) s_child = 0, s_sh = 0;
-    __syncthreads();
-    const int n_pad = (n + 63) & ~63; // whole waves iterate together: the ballots need every lane
-    for (int j = threadIdx.x; j < n_pad; j += WF_BLOCK) {
-        const bool   valid = j < n;
-        const size_t i = base + j;
-        uint2        meta = make_uint2(0, 0);
-        float4       ow = make_float4(0, 0, 0, 0), dn = make_float4(0, 0, 0, 0), hit = make_float4(0, 0, 0, 0);
-        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = in.hits[i];
-        const int   orig = valid ? __float_as_int(hit.x) : -1;
-        const int   k = (int)(meta.y & 0xff);
-        bool        shared = (meta.y >> 8) & 1;
-        const f3    o = mk3(ow.x, ow.y, ow.z), dst = mk3(dn.x, dn.y, dn.z);
-        const float w = ow.w;
-        if (valid && k == 0) { // the camera ray fixes the sample's depth and triangle
-            B.s_minT[meta.x] = hit.w;
-            B.s_tri[meta.x] = orig;
-        }
-        float      wl = 0.0f;
-        WfSurf     s;
-        const bool is_hit = valid && orig >= 0;
-        if (valid && !is_hit) // raytracing.cpp:74
-            wf_acc_add(B, meta.x, mk3(P.bg[0], P.bg[1], P.bg[2]) * w, shared);
-        if (is_hit) wf_surface(S, o, dst, hit, s), ++n_shaded;
-        // ---- shadow rays: one queue for all lights (a wave of shadow rays then is full whatever
-        // the share of each light; rays of one light and one wave of hits stay neighbours) ----
-        float shadowMax = 0.0f;
-        for (int li = 0; li < P.n_lights; ++li) {
-            bool cast = false;
-            f3   lightDir = mk3(0, 0, 0);
-            if (is_hit) {
-                float angle;
-                cast = wf_light_setup(s, mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]),
-                                      lightDir, angle, shadowMax);
-                // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
-                // shadowMax is its value with every query so far answered "free"; if that is 1
-                // already - set by a grazing angle at this light, or carried from an earlier one -
-                // the answer cannot change the colour and the query is not traced.  (Soft shadows
-                // take the maximum with a sum that rounding may carry past 1: all of them are traced.)
-                if (!SOFT && shadowMax == 1.0f) cast = false;
-                shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax;
-            }
-            const int pos = wf_append(&s_sh, cast, SOFT ? B.ns : 1);
-            if (cast) {
-                const f3  so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
-                const int tag = (li << 24) | j;
-                if (!SOFT) {
-                    B.sh_org[sbase + pos] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
-                } else { // raytracing.cpp:145-160: ns rays towards jittered points around the light
-                    const int slot = P.msaa == 1 ? (int)meta.x : (int)(meta.x / (unsigned)P.msaa);
-                    const int sn = P.msaa == 1 ? 0 : (int)(meta.x % (unsigned)P.msaa) + 1;
-                    int       px = 0, py = 0;
-                    slot_to_pixel(P, slot0 + slot, px, py);
-                    const unsigned long long id = ((unsigned long long)py * P.W + px) * 32 + sn;
-                    const size_t             q0 = sbase + pos;
-                    B.occl[(size_t)li * B.cap + i] = 0;
-                    for (int si = 0; si < B.ns; ++si) {
-                        float4 dd = make_float4(0, 0, 0, 0);
-                        soft_dest(&P.lights[0], &P.soft_x[0], P.soft_n, P.soft_half, P.soft_quarter, P.soft_radius, li, si, id,
-                                  (meta.y >> 16) & 0xffu, dd.x, dd.y, dd.z);
-                        B.sh_org[q0 + si] = make_float4(so.x, so.y, so.z, __int_as_float(tag));
-                        B.sh_dst[q0 + si] = dd;
-                    }
-                }
-            }
-        }
-        // ---- children, raytracing.cpp:166-271 ----
-        int      nchild = 0;
-        f3       c_o[2], c_d[2];
-        float    c_w[2];
-        unsigned c_kind[2] = {0, 0}; // 1 mirror, 2 transmitted, 3 reflected (the soft-shadow generator's key)
-        float n2 = 1.0f;
-        if (is_hit) {
-            wl = w;
-            const int newK = k + 1;
-            if (newK < 5) {
-                const float n1 = (dn.w != 0.0f) ? dn.w : 1.0f;
-                n2 = s.has_Ni ? s.Ni : 1.0f;
-                if (s.illum == 3) {
-                    const f3 refl = s.dir - s.N * (2.0f * dot3(s.N, s.dir));
-                    wl = 0.5f * w;
-                    c_o[0] = s.hp + refl * 0.001f, c_d[0] = s.hp + refl, c_w[0] = 0.5f * w, c_kind[0] = 1;
-                    nchild = 1;
-                } else if (s.Ni > 1.0f) {
-                    f3 I = s.dir;
-                    normalize3(I);
-                    const float eta = (n1 != n2) ? n2 : __fdiv_rn(1.0f, n2);
-                    const float cosI = dot3(I, s.N);
-                    const float sin2T =
-                        (float)(((double)eta * (double)eta) * (1.0 - ((double)cosI * (double)cosI)));
-                    float rf = sin2T;
-                    rf = rf < 0.0f ? 0.0f : rf;
-                    rf = rf > 1.0f ? 1.0f : rf;
-                    float wLocal = 0.5f * rf;
-                    if (sin2T <= 1.0f) {
-                        const float f = (float)((double)(eta * cosI) - sqrt((double)(1.0f - sin2T)));
-                        const f3    tRay = I * eta + s.N * f;
-                        wLocal += 0.1f * (1.0f - rf);
-                        const float wT = 0.9f * (1.0f - rf) * w;
-                        if (wT != 0.0f) {
-                            c_o[nchild] = s.hp + tRay * 0.001f, c_d[nchild] = s.hp + tRay, c_w[nchild] = wT;
-                            c_kind[nchild] = 2;
-                            ++nchild;
-                        }
-                    }
-                    const float wR = 0.5f * rf * w;
-                    if (wR != 0.0f) {
-                        const f3 refRay = I - s.N * (2.0f * dot3(I, s.N));
-                        c_o[nchild] = s.hp + refRay * 0.001f, c_d[nchild] = s.hp + refRay, c_w[nchild] = wR;
-                        c_kind[nchild] = 3;
-                        ++nchild;
-                    }
-                    wl = wLocal * w;
-                    shared = shared || nchild > 1;
-                }
-            }
-        }
-        if (valid) B.wlocal[i] = wl;
-        n_child += nchild;
-        for (int c = 0; c < 2; ++c) {
-            const bool mine = c < nchild;
-            const int  pos = wf_append(&s_child, mine);
-            if (mine && pos < B.R) { // cannot exceed R by construction; the guard keeps a bug from writing outside
-                const size_t p = base + pos;
-                out.o_w[p] = make_float4(c_o[c].x, c_o[c].y, c_o[c].z, c_w[c]);
-                out.d_ni[p] = make_float4(c_d[c].x, c_d[c].y, c_d[c].z, n2);
-                unsigned my = (unsigned)(k + 1) | ((shared ? 1u : 0u) << 8);
-                if (SOFT) my |= ((((meta.y >> 16) & 0x3fu) << 2) | c_kind[c]) << 16; // the generator's key
-                out.meta[p] = make_uint2(meta.x, my);
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) out.cnt[r] = min(s_child, B.R);
-    if (threadIdx.x == 0) B.sh_cnt[r] = s_sh;
-}
-
+// MSAA > 1, after the centre rays (queue 1) are traced: misses are final pixels; every hit
+// pixel queues its `msaa` sample rays (main.cpp:445-507) into region r of queue 0.
 __global__ void __launch_bounds__(WF_BLOCK)
-k_wf_shade(DScene S, DParams P, WfBuffers B, int level, DCounters* ctr)
+k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth, int* tri,
+               unsigned char* centre_hit, DCounters* ctr)
 {
-    __shared__ WfShared sh;
-    unsigned            n_shaded = 0, n_child = 0;
-    wf_shade_region(S, P, B, B.rays[level & 1], B.rays[(level + 1) & 1], blockIdx.x, &sh, n_shaded, n_child);
-    for (int s = 32; s > 0; s >>= 1) n_shaded += __shfl_down(n_shaded, s), n_child += __shfl_down(n_child, s);
-    if ((threadIdx.x & 63) == 0 && (n_shaded | n_child)) {
-        atomicAdd(&ctr->shaded_hits, (unsigned long long)n_shaded);
-        atomicAdd(&ctr->child_rays, (unsigned long long)n_child);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// resolve: the light loop of raytracing.cpp:110-164 with the shadow queries answered
-// ---------------------------------------------------------------------------
-template <bool SOFT = false, class ST = DScene, class PT = DParams>
-__device__ __forceinline__ void wf_resolve_region(const ST& S_, const PT& P, const WfBuffers& B,
-                                                  const WfRays in, int r)
-{
-    const DScene S = wf_scene(S_);
-    const int    n = in.cnt[r];
-    const size_t base = (size_t)r * B.R;
-    const float  shadowPart = __fdiv_rn(P.ShadowFactor, (float)P.n_lights); // raytracing.cpp:102
-    for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
-        const size_t i = base + j;
-        const float  wl = B.wlocal[i];
-        const float4 hit = in.hits[i];
-        if (__float_as_int(hit.x) < 0) continue;
-        const uint2  meta = in.meta[i];
-        const float4 ow = in.o_w[i], dn = in.d_ni[i];
-        WfSurf       s;
-        wf_surface(S, mk3(ow.x, ow.y, ow.z), mk3(dn.x, dn.y, dn.z), hit, s);
-        f3 res;
-        if (s.tex < 0) res = s.Kd * P.backgroundlighting; // raytracing.cpp:92-95
-        else res = sample_texture(S, s.tex, s.info, s.hp);
-        float shadowMax = 0.0f; // carried from light to light (raytracing.cpp:104)
-        for (int li = 0; li < P.n_lights; ++li) {
-            const f3 lpos = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
-            f3       lightDir = lpos - s.hp;
-            normalize3(lightDir);
-            float angle = dot3(s.N, lightDir);
-            if (angle > 0.0f) res = res + (s.Kd * angle) * P.diffusePower;
-            angle = dot3(lightDir, s.N);
-            if (angle <= 0.2f) shadowMax = 1.0f;
-            else if (angle < 0.5f) {
-                angle -= 0.2f;
-                shadowMax = 3.33f * (0.3f - angle);
-            }
-            if (angle > 0.0f) {
-                f3 halfway = lightDir + s.viewDir;
-                normalize3(halfway);
-                angle = dot3(s.N, halfway);
-                if (angle > 0.0f) res = res + s.Ks * powf(angle, s.Ns);
-                const int occluded = B.occl[(size_t)li * B.cap + i];
-                if (!SOFT) {
-                    if (occluded) shadowMax = 1.0f;
-                } else { // raytracing.cpp:155-157: one float addition per occluded sample
-                    float softShadow = 0.0f;
-                    for (int c = 0; c < occluded; ++c) softShadow += P.soft_w;
-                    shadowMax = (shadowMax < softShadow) ? softShadow : shadowMax;
-                }
-            }
-            shadowMax = (shadowMax < 0.0f) ? 0.0f : shadowMax; // std::max(shadowMax, softShadow) with softShadow >= 0
-            const float sm = shadowMax * shadowPart;
-            res = res - mk3(sm, sm, sm);
-        }
-        wf_acc_add(B, meta.x, res * wl, (meta.y >> 8) & 1);
-    }
-}
-
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_resolve(DScene S, DParams P, WfBuffers B, int level)
-{
-    wf_resolve_region(S, P, B, B.rays[level & 1], blockIdx.x);
-}
-
-// ---------------------------------------------------------------------------
-// camera rays
-// ---------------------------------------------------------------------------
-// Block r: centre rays of pixel slots slot0 + [r * S, (r + 1) * S) that lie inside
-// the frame, appended to region r of queue 0.  meta.x = slot - slot0.
-template <class PT>
-__device__ __forceinline__ void wf_gen_region(const PT& P, const WfBuffers& B, const WfRays q,
-                                              long long slot0, int n, DCounters* ctr, int r, WfShared* sh)
-{
-    int&         s_n = sh->n;
-    const size_t base = (size_t)r * B.R;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int s_pad = (B.S + 63) & ~63;
-    for (int j = threadIdx.x; j < s_pad; j += WF_BLOCK) {
-        const int i = j < B.S ? r * B.S + j : n;
-        int       x = 0, y = 0;
-        const bool valid = i < n && slot_to_pixel(P, slot0 + i, x, y);
-        const int  pos = wf_append(&s_n, valid);
-        if (valid) {
-            f3 o, d;
-            pixel_ray(P, (double)x, (double)y, o, d);
-            q.o_w[base + pos] = make_float4(o.x, o.y, o.z, 1.0f);
-            q.d_ni[base + pos] = make_float4(d.x, d.y, d.z, 1.0f); // prev_Ni = 1.0f (main.cpp:528)
-            q.meta[base + pos] = make_uint2((unsigned)i, 0u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        q.cnt[r] = s_n;
-        atomicAdd(&ctr->camera_rays, (unsigned long long)s_n);
-    }
-}
-
-__global__ void __launch_bounds__(WF_BLOCK)
-k_wf_gen_centre(DParams P, WfBuffers B, long long slot0, int n, DCounters* ctr)
-{
-    __shared__ WfShared sh;
-    wf_gen_region(P, B, B.rays[0], slot0, n, ctr, blockIdx.x, &sh);
-}
-
-// MSAA > 1, after the centre rays are traced: misses are final pixels; every hit
-// pixel queues its `msaa` sample rays (main.cpp:445-507) into region r of queue 1.
-// Sample index = (slot - slot0) * msaa + s.
-template <class PT>
-__device__ __forceinline__ void wf_msaa_region(const PT& P, const WfBuffers& B, const WfRays in,
-                                               const WfRays q, long long slot0, float* rgb, float* depth,
-                                               int* tri, unsigned char* centre_hit, DCounters* ctr, int r,
-                                               WfShared* sh)
-{
-    int&         s_n = sh->n;
-    const int    n = in.cnt[r];
-    const size_t base = (size_t)r * B.R;
+    __shared__ int s_n;
+    const int      r = blockIdx.x;
+    const WfRays   in = B.rays[1], out = B.rays[0];
+    const int      n = in.cnt[r];
+    const size_t   base = (size_t)r * B.R;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int n_pad = (n + 63) & ~63;
@@ -714,19 +807,14 @@ __device__ __forceinline__ void wf_msaa_region(const PT& P, const WfBuffers& B, 
         bool       got = false;
         int        x = 0, y = 0, slot = 0;
         if (valid) {
-            slot = (int)in.meta[base + j].x;
-            const float4 hit = in.hits[base + j];
+            slot = (int)(in.meta[base + j] & 0xffffu);
+            const float4 hit = B.hits[base + j];
             got = __float_as_int(hit.x) >= 0;
-            slot_to_pixel(P, slot0 + slot, x, y);
+            slot_to_pixel(P, slot0 + (long long)r * B.S + slot, x, y);
             const size_t p = (size_t)y * P.W + x;
             if (tri) tri[p] = __float_as_int(hit.x);
-            centre_hit[slot] = got ? 1 : 0;
-            if (!got) {
-                rgb[3 * p] = wf_clamp01(P.bg[0]);
-                rgb[3 * p + 1] = wf_clamp01(P.bg[1]);
-                rgb[3 * p + 2] = wf_clamp01(P.bg[2]);
-                depth[p] = RT_FLT_MAX;
-            }
+            centre_hit[(size_t)r * B.S + slot] = got ? 1 : 0;
+            if (!got) wf_background_pixel(P, p, rgb, depth);
         }
         const int pos = wf_append(&s_n, got, P.msaa);
         if (got && pos + P.msaa <= B.R) {
@@ -736,68 +824,55 @@ __device__ __forceinline__ void wf_msaa_region(const PT& P, const WfBuffers& B, 
                 f3          o, d;
                 pixel_ray(P, (double)x + (double)ox, (double)y + (double)oy, o, d);
                 const size_t p = base + pos + s;
-                q.o_w[p] = make_float4(o.x, o.y, o.z, 1.0f);
-                q.d_ni[p] = make_float4(d.x, d.y, d.z, 1.0f);
-                q.meta[p] = make_uint2((unsigned)(slot * P.msaa + s), 0u);
+                out.o_w[p] = make_float4(o.x, o.y, o.z, 1.0f);
+                out.d_ni[p] = make_float4(d.x, d.y, d.z, 1.0f);
+                out.meta[p] = wf_meta((unsigned)(slot * P.msaa + s), 0u, 0u);
             }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        q.cnt[r] = min(s_n, B.R);
+        out.cnt[r] = min(s_n, B.R);
         atomicAdd(&ctr->camera_rays, (unsigned long long)s_n);
     }
 }
 
+// Block r: the rays of level `level` of region r, traced before (hit records).
 __global__ void __launch_bounds__(WF_BLOCK)
-k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth, int* tri,
-               unsigned char* centre_hit, DCounters* ctr)
+k_wf_shade(DScene S, DParams P, WfBuffers B, int level, long long slot0, DCounters* ctr)
 {
-    __shared__ WfShared sh;
-    wf_msaa_region(P, B, B.rays[0], B.rays[1], slot0, rgb, depth, tri, centre_hit, ctr, blockIdx.x, &sh);
-}
-
-// Pixels from sample sums.  MSAA == 1: sample index = slot - slot0.  MSAA > 1:
-// ordered float sum of the samples / msaa, depth = mean of minT over the samples
-// that hit (main.cpp:449-507); only pixels whose centre ray hit.
-template <class PT>
-__device__ __forceinline__ void wf_finalize_slot(const PT& P, const WfBuffers& B, long long slot0, int i,
-                                                 const unsigned char* __restrict__ centre_hit, float* rgb,
-                                                 float* depth, int* tri)
-{
-    int x, y;
-    if (!slot_to_pixel(P, slot0 + i, x, y)) return;
-    const size_t p = (size_t)y * P.W + x;
-    const size_t ns = (size_t)B.n_samples;
-    if (P.msaa == 1) {
-        const float r = (float)((double)B.acc[i] / WF_FIX_SCALE);
-        const float g = (float)((double)B.acc[ns + i] / WF_FIX_SCALE);
-        const float b = (float)((double)B.acc[2 * ns + i] / WF_FIX_SCALE);
-        rgb[3 * p] = wf_clamp01(r);
-        rgb[3 * p + 1] = wf_clamp01(g);
-        rgb[3 * p + 2] = wf_clamp01(b);
-        depth[p] = B.s_minT[i];
-        if (tri) tri[p] = B.s_tri[i];
-        return;
+    __shared__ int s_child, s_sh;
+    const int      r = blockIdx.x;
+    const WfRays   in = B.rays[level & 1], out = B.rays[(level + 1) & 1];
+    const int      n = in.cnt[r];
+    unsigned       n_shaded = 0, n_child = 0;
+    WfRegion<WfAcc> g;
+    g.base = (size_t)r * B.R, g.sample0 = (size_t)r * B.S * P.msaa, g.slot_base = slot0 + (long long)r * B.S;
+    g.par = level & 1, g.n_child = &s_child, g.n_sh = &s_sh;
+    g.acc.at = B.acc, g.acc.n = (unsigned)B.n_samples, g.acc0 = (unsigned)g.sample0;
+    if (threadIdx.x == 0) s_child = 0, s_sh = 0;
+    __syncthreads();
+    const int n_pad = (n + 63) & ~63; // whole waves iterate together: the ballots need every lane
+    for (int j = threadIdx.x; j < n_pad; j += WF_BLOCK) {
+        const bool   valid = j < n;
+        const size_t i = g.base + j;
+        unsigned     meta = 0;
+        float4       ow = make_float4(0, 0, 0, 0), dn = make_float4(0, 0, 0, 0), hit = make_float4(0, 0, 0, 0);
+        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = B.hits[i];
+        const f3 o = mk3(ow.x, ow.y, ow.z);
+        wf_shade_ray<false>(S, P, B, out, g, valid, j, o, mk3(dn.x, dn.y, dn.z) - o, ow.w, dn.w, meta,
+                            __float_as_int(hit.x) >= 0, __float_as_int(hit.x), hit.y, hit.z, hit.w, n_shaded, n_child);
     }
-    if (!centre_hit[i]) return;
-    float r = 0, g = 0, b = 0, dsum = 0;
-    int   hits = 0;
-    for (int s = 0; s < P.msaa; ++s) {
-        const size_t k = (size_t)i * P.msaa + s;
-        const float  sr = (float)((double)B.acc[k] / WF_FIX_SCALE);
-        const float  sg = (float)((double)B.acc[ns + k] / WF_FIX_SCALE);
-        const float  sb = (float)((double)B.acc[2 * ns + k] / WF_FIX_SCALE);
-        if (s == 0) r = sr, g = sg, b = sb;
-        else r += sr, g += sg, b += sb;
-        const float mt = B.s_minT[k];
-        if (mt != RT_FLT_MAX) dsum += mt, ++hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out.cnt[r] = min(s_child, B.R);
+        B.sh_cnt[(size_t)(level & 1) * B.G + r] = s_sh;
     }
-    const float nn = (float)P.msaa;
-    rgb[3 * p] = wf_clamp01(__fdiv_rn(r, nn));
-    rgb[3 * p + 1] = wf_clamp01(__fdiv_rn(g, nn));
-    rgb[3 * p + 2] = wf_clamp01(__fdiv_rn(b, nn));
-    depth[p] = hits > 0 ? __fdiv_rn(dsum, (float)hits) : RT_FLT_MAX;
+    for (int s = 32; s > 0; s >>= 1) n_shaded += __shfl_down(n_shaded, s), n_child += __shfl_down(n_child, s);
+    if ((threadIdx.x & 63) == 0 && (n_shaded | n_child)) {
+        atomicAdd(&ctr->shaded_hits, (unsigned long long)n_shaded);
+        atomicAdd(&ctr->child_rays, (unsigned long long)n_child);
+    }
 }
 
 __global__ void __launch_bounds__(WF_BLOCK)
@@ -805,7 +880,11 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
               float* rgb, float* depth, int* tri)
 {
     const int i = blockIdx.x * WF_BLOCK + threadIdx.x;
-    if (i < n) wf_finalize_slot(P, B, slot0, i, centre_hit, rgb, depth, tri);
+    if (i >= n || (P.msaa > 1 && !centre_hit[i])) return;
+    int x, y;
+    if (!slot_to_pixel(P, slot0 + i, x, y)) return;
+    const WfAcc acc = {B.acc, (unsigned)B.n_samples};
+    wf_finalize_pixel(P, B, acc, (unsigned)(i * P.msaa), (size_t)y * P.W + x, (size_t)i * P.msaa, rgb, depth, tri);
 }
 
 // ---------------------------------------------------------------------------
@@ -825,86 +904,12 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
 // coarse first (the chain of dependent stages does not get shorter with fewer rays, and
 // regions below 64 slots leave most of a block's waves empty: 16 slots 5.9 ms vs 2.6 ms for
 // an eighth of a 4K frame).
-// A block takes a region (one atomic), runs every stage of its pixels - camera rays,
-// MSAA gating, five levels of trace / shade / shadow trace / resolve, pixel resolve - and
-// takes the next region.  Stages of a region are separated by block barriers only; there
-// is no device-wide synchronisation and no launch boundary inside the frame, so a CU
-// always has other blocks' stages to run while one block waits for its slowest ray, and
-// the bandwidth-bound stages of some blocks overlap the arithmetic-bound traces of others.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void wf_trace_region(const DScene& S, const float4* __restrict__ o_w,
-                                                const float4* __restrict__ d_ni, f3 light, int n,
-                                                size_t base, float4* hits, unsigned char* occl,
-                                                const WfStack& stk, unsigned& n_tests, unsigned& n_nodes,
-                                                unsigned& n_rays)
-{
-    for (int j = threadIdx.x; j < n; j += WF_BLOCK) {
-        const size_t i = base + j;
-        const float4 ow = o_w[i];
-        const f3     o = mk3(ow.x, ow.y, ow.z);
-        f3           dst = light;
-        if (!ANY) {
-            const float4 dn = d_ni[i];
-            dst = mk3(dn.x, dn.y, dn.z);
-        }
-        HitRec h;
-        ++n_rays;
-        const bool got = wf_traverse<ANY, COUNT>(S, stk, o, dst - o, h, n_tests, n_nodes);
-        if (ANY) occl[__float_as_int(ow.w)] = got ? 1 : 0;
-        else hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
-    }
-}
-
-// Shadow queries of one level and closest-hit queries of the next in one pass: both sets
-// of rays come out of the same shade stage and neither needs the other's answers, so a
-// region's chain of dependent stages is one trace per level instead of two.  The index
-// space is [closest rays][shadow rays], each segment padded to whole waves so a wave runs one
-// kind of walk; the closest-hit rays (the longer walks) start first.
-template <bool COUNT, bool SOFT = false, class PT = DParams>
-__device__ __forceinline__ void wf_trace_merged(const DScene& S, const PT& P, const WfBuffers& B,
-                                                const WfRays next, int n_next, int r, const WfStack& stk,
-                                                unsigned& n_tests, unsigned& n_nodes, unsigned& n_closest,
-                                                unsigned& n_shadow)
-{
-    const size_t base = (size_t)r * B.R;
-    const int    seg_c = (n_next + 63) & ~63;
-    const int    n_sh = B.sh_cnt[r];
-    const int    total = seg_c + n_sh;
-    const size_t sbase = base * P.n_lights * (SOFT ? B.ns : 1);
-    for (int i = threadIdx.x; i < total; i += WF_BLOCK) {
-        if (i < seg_c) {
-            if (i >= n_next) continue;
-            const size_t k = base + i;
-            const float4 ow = next.o_w[k], dn = next.d_ni[k];
-            const f3     o = mk3(ow.x, ow.y, ow.z);
-            HitRec       h;
-            ++n_closest;
-            const bool got = wf_traverse<false, COUNT>(S, stk, o, mk3(dn.x, dn.y, dn.z) - o, h, n_tests, n_nodes);
-            next.hits[k] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
-        } else {
-            const size_t qi = sbase + (i - seg_c);
-            const float4 ow = B.sh_org[qi];
-            const f3     o = mk3(ow.x, ow.y, ow.z);
-            const int    li = (int)((unsigned)__float_as_int(ow.w) >> 24);
-            const size_t hit_slot = base + (size_t)(__float_as_int(ow.w) & 0xffffff);
-            f3           l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
-            if (SOFT) {
-                const float4 dd = B.sh_dst[qi];
-                l = mk3(dd.x, dd.y, dd.z);
-            }
-            HitRec h;
-            ++n_shadow;
-            const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, n_tests, n_nodes);
-            if (!SOFT) {
-                B.occl[(size_t)li * B.cap + hit_slot] = got ? 1 : 0;
-            } else if (got) { // count in the hit's byte (at most 216 samples): add into its 32-bit word
-                const size_t b = (size_t)li * B.cap + hit_slot;
-                atomicAdd((unsigned*)(B.occl + (b & ~(size_t)3)), 1u << (8 * (unsigned)(b & 3)));
-            }
-        }
-    }
-}
-
+// A block takes a region (one atomic), runs every stage of its pixels - centre rays and MSAA
+// gating, camera samples, five levels of child and shadow rays, pixel resolve - and takes the
+// next region.  Stages of a region are separated by block barriers only; there is no
+// device-wide synchronisation and no launch boundary inside the frame, so a CU always has
+// other blocks' stages to run while one block waits for its slowest ray.
+//
 // Compiled for 7 waves per SIMD (72 VGPRs; what does not fit spills, outside the traversal
 // loops).  Measured per 4K frame: 25.6 / 23.6 / 23.3 / 22.6 / 25.4 ms for 4 / 5 / 6 / 7 / 8.
 #ifndef WF_PIPE_WAVES
@@ -928,16 +933,15 @@ __device__ unsigned long long g_timeline[WF_TL_REGIONS * 16];
 // fetched back with v_readlane - from the moment two more fields were added to WfBuffers also
 // inside the node and triangle loops (16 reloads per iteration, 13.0 vs 12.0 ms per 4K frame).
 struct WfLaunch {
-    DScene         S;
-    DParams        P;
-    WfBuffers      B;
-    long long      slot0;
-    int            n, n_regions; // pixel slots of the frame part, regions of B.S slots they make
-    float*         rgb;
-    float*         depth;
-    int*           tri;
-    unsigned char* centre_hit;
-    DCounters*     ctr;
+    DScene     S;
+    DParams    P;
+    WfBuffers  B;
+    long long  slot0;
+    int        n, n_regions; // pixel slots of the frame part, regions of B.S slots they make
+    float*     rgb;
+    float*     depth;
+    int*       tri;
+    DCounters* ctr;
 };
 typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
 
@@ -955,14 +959,134 @@ __device__ __forceinline__ T wf_ld(const __attribute__((address_space(4))) T& sr
 #endif
 }
 
-__device__ __forceinline__ DScene wf_scene(const DScene& s) { return s; }
-__device__ __forceinline__ DScene wf_scene(const __attribute__((address_space(4))) DScene& s) { return wf_ld(s); }
-
 __device__ __forceinline__ WfLaunchC wf_args()
 {
     WfLaunchC p = (WfLaunchC)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
+}
+
+struct WfStat {
+    unsigned n_tests, n_nodes, n_shaded, n_child;
+};
+
+#define WF_ST_CENTRE 0 // MSAA > 1: the pixel-centre rays that gate the samples (main.cpp:435-445)
+#define WF_ST_CAMERA 1 // level 0: one ray per pixel, or msaa per pixel whose centre hit
+#define WF_ST_LEVEL 2  // closest hits of level `level` and the shadow rays of the level before
+
+// One stage of region r, run by block qr on its own set of buffers.  The index space is
+// [closest-hit rays, padded to whole waves][shadow rays]: a wave runs one kind of walk, the
+// closest-hit rays (the longer walks) start first.  Shadow queries of one level and closest-hit
+// queries of the next come out of the same shade step and neither needs the other's answers, so
+// a region's chain of dependent stages is one pass per level.
+template <bool COUNT, bool SOFT>
+__device__ __forceinline__ void wf_stage(const int kind, const int level, const int r, const int qr, WfShared* sh,
+                                         unsigned char* s_mem, WfStat& st)
+{
+    const WfLaunchC A = wf_args();
+    const DScene    S = wf_ld(A->S);
+    const WfBuffers B = wf_ld(A->B);
+    const auto&     P = A->P;
+    const WfStack   stk = wf_stack(S, s_mem);
+    const int       msaa = P.msaa;
+    const int       n_slots = A->n - r * B.S; // pixel slots from the region's first to the end of the frame part
+    WfRegion<WfAccL> g;
+    g.base = (size_t)qr * B.R, g.sample0 = (size_t)qr * B.S * msaa;
+    g.slot_base = A->slot0 + (long long)r * B.S;
+    g.par = level & 1, g.n_child = &sh->child[(level + 1) % 3], g.n_sh = &sh->shd[level % 3];
+    g.acc.at = (WfLdsSums)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES); // after the stacks
+    g.acc.n = (unsigned)(B.S * msaa), g.acc0 = 0;
+    int n_first = B.S, n_sh = 0;
+    if (kind == WF_ST_CAMERA && msaa > 1) n_first = sh->n_hit * msaa;
+    if (kind == WF_ST_LEVEL) n_first = sh->child[level % 3], n_sh = sh->shd[(level + 2) % 3];
+    if (kind != WF_ST_CENTRE && threadIdx.x == 0) // the outputs of the stage after this one
+        sh->child[(level + 2) % 3] = 0, sh->shd[(level + 1) % 3] = 0;
+    const WfRays in = wf_ld(A->B.rays[level & 1]), out = wf_ld(A->B.rays[(level + 1) & 1]);
+    const int    seg_c = (n_first + 63) & ~63;
+    const int    total = seg_c + n_sh;
+    const int    lane = threadIdx.x & 63;
+    const size_t sq_in = ((size_t)((level + 1) & 1) * B.cap + g.base) * P.n_lights * (SOFT ? B.ns : 1);
+    for (int i0 = (int)threadIdx.x - lane; i0 < total; i0 += WF_BLOCK) {
+        const int idx = i0 + lane;
+        if (i0 < seg_c) {
+            // Before the walk only the ray itself is formed; whatever else the shading needs (weight,
+            // prev_Ni, sample, queue addresses) is fetched or derived again afterwards from the
+            // lane's index, so that it does not sit in registers - or in scratch - during the walk.
+            bool valid = idx < n_first;
+            f3   o = mk3(0, 0, 0), dst = mk3(0, 0, 0);
+            int  xy = 0;
+            if (kind == WF_ST_LEVEL) {
+                if (valid) {
+                    const float4 ow = in.o_w[g.base + idx], dn = in.d_ni[g.base + idx];
+                    o = mk3(ow.x, ow.y, ow.z), dst = mk3(dn.x, dn.y, dn.z);
+                }
+            } else {
+                int x = 0, y = 0, sn = -1;
+                if (kind == WF_ST_CAMERA && msaa > 1) { // pixel of a centre hit, as the centre stage left it
+                    xy = valid ? B.hit_list[(size_t)qr * B.S + idx / msaa].y : 0;
+                    x = xy & 0xffff, y = xy >> 16;
+                    sn = idx % msaa;
+                } else {
+                    valid = valid && idx < n_slots && slot_to_pixel(P, g.slot_base + idx, x, y);
+                    xy = x | (y << 16);
+                }
+                if (valid) {
+                    double fx = (double)x, fy = (double)y;
+                    if (sn >= 0) {
+                        fx += (double)(msaa == 4 ? c_msaa4[sn][0] : c_msaa16[sn][0]);
+                        fy += (double)(msaa == 4 ? c_msaa4[sn][1] : c_msaa16[sn][1]);
+                    }
+                    pixel_ray(P, fx, fy, o, dst);
+                }
+                const unsigned long long cam = __ballot(valid);
+                if (lane == 0 && cam) atomicAdd(&sh->n_cam, (int)__popcll(cam));
+            }
+            {
+                const unsigned long long m = __ballot(valid);
+                if (lane == 0 && m) atomicAdd(&sh->n_closest, (int)__popcll(m));
+            }
+            const f3 dir = dst - o;
+            HitRec   h;
+            h.slot = -1, h.a = 0.0f, h.b = 0.0f, h.t = RT_FLT_MAX;
+            bool got = false;
+            if (valid) got = wf_traverse<false, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
+            int j = idx;
+            asm volatile("" : "+v"(j)); // what follows is computed after the walk, not carried through it
+            if (kind == WF_ST_CENTRE) { // misses are final pixels, hits queue their samples
+                if (valid) {
+                    const size_t p = (size_t)(xy >> 16) * P.W + (xy & 0xffff);
+                    if (A->tri) A->tri[p] = h.slot;
+                    if (!got) wf_background_pixel(P, p, A->rgb, A->depth);
+                }
+                const int pos = wf_append(&sh->n_hit, valid && got);
+                if (valid && got) B.hit_list[(size_t)qr * B.S + pos] = make_int2(j, xy);
+            } else {
+                float    w = 1.0f, ni = 1.0f; // prev_Ni = 1.0f for camera rays (main.cpp:528)
+                unsigned meta = 0;
+                if (valid) {
+                    if (kind == WF_ST_LEVEL) w = in.o_w[g.base + j].w, ni = in.d_ni[g.base + j].w, meta = in.meta[g.base + j];
+                    else if (msaa > 1) meta = wf_meta((unsigned)(B.hit_list[(size_t)qr * B.S + j / msaa].x * msaa + j % msaa), 0u, 0u);
+                    else meta = wf_meta((unsigned)j, 0u, 0u);
+                }
+                wf_shade_ray<SOFT>(S, P, B, out, g, valid, j, o, dir, w, ni, meta, got, h.slot, h.a, h.b, h.t,
+                                   st.n_shaded, st.n_child);
+            }
+        } else if (idx < total) {
+            const float4 ow = B.sh_org[sq_in + (idx - seg_c)];
+            const f3     o = mk3(ow.x, ow.y, ow.z);
+            const int    li = (int)((unsigned)__float_as_int(ow.w) >> 24);
+            f3           l = mk3(P.lights[3 * li], P.lights[3 * li + 1], P.lights[3 * li + 2]);
+            if (SOFT) {
+                const float4 dd = B.sh_dst[sq_in + (idx - seg_c)];
+                l = mk3(dd.x, dd.y, dd.z);
+            }
+            HitRec h;
+            if (idx == i0) atomicAdd(&sh->n_shadow, min(64, total - i0));
+            const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, st.n_tests, st.n_nodes);
+            wf_shadow_done<SOFT>(P, B, (size_t)((level + 1) & 1) * B.cap + g.base + (__float_as_int(ow.w) & 0xffffff),
+                                 g.acc, g.acc0, li, got);
+        }
+    }
 }
 
 template <bool COUNT, bool SOFT>
@@ -971,137 +1095,77 @@ k_wf_pipeline(WfLaunch)
 {
     extern __shared__ __align__(16) unsigned char s_mem[];
     __shared__ WfShared sh;
-    unsigned            n_tests = 0, n_nodes = 0, n_closest = 0, n_shadow = 0, n_shaded = 0, n_child = 0;
+    WfStat              st = {0, 0, 0, 0};
+    // The workspace has one set of queues, records, colour sums and lists per block, not per
+    // region: the block runs region r on set qr.  Consecutive regions of a block reuse the same few
+    // hundred KB (11.5 -> 10.6 ms per 4K frame against a set per region), and the workspace does
+    // not grow with the frame.
+    const int qr = blockIdx.x;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
+        if (threadIdx.x == 0) {
+            sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
+            sh.child[1] = 0, sh.shd[0] = 0, sh.n_hit = 0, sh.n_cam = 0; // what the camera stage appends to
+            sh.n_closest = 0, sh.n_shadow = 0;
+        }
         __syncthreads();
         const int r = sh.region;
         if (r >= wf_args()->n_regions) break;
-        // The workspace has one set of queues, colour sums and flags per block, not per region: the
-        // block runs region r as "region qr" of the buffers, with the first pixel slot and the slot
-        // count shifted to match.  Consecutive regions of a block reuse the same few hundred KB,
-        // which stay in the L2 of its XCD instead of streaming through HBM (11.5 -> 11.1 ms per 4K
-        // frame), and the workspace does not grow with the frame.
-        const int qr = blockIdx.x;
-#define WF_SLOT0(A) ((A)->slot0 + (long long)(r - qr) * (A)->B.S)
-#define WF_N(A) ((A)->n + (qr - r) * (A)->B.S)
         WF_TL(0);
 #ifdef WF_TIMELINE
         if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + 15] = blockIdx.x;
 #endif
-        {
-            const WfLaunchC A = wf_args();
-            const WfBuffers B = wf_ld(A->B);
-            const size_t    ns = (size_t)B.n_samples;
-            const int       msaa = A->P.msaa;
-            for (int j = threadIdx.x; j < B.S * msaa; j += WF_BLOCK) { // this region's colour sums
-                const size_t k = (size_t)qr * B.S * msaa + j;
-                B.acc[k] = 0, B.acc[ns + k] = 0, B.acc[2 * ns + k] = 0;
-            }
-            wf_gen_region(A->P, B, wf_ld(A->B.rays[0]), WF_SLOT0(A), WF_N(A), A->ctr, qr, &sh);
-        }
-        __syncthreads();
-        {
-            const WfLaunchC A = wf_args();
-            const DScene    S = wf_ld(A->S);
-            const WfRays    q0 = wf_ld(A->B.rays[0]);
-            wf_trace_region<false, COUNT>(S, q0.o_w, q0.d_ni, mk3(0, 0, 0), q0.cnt[qr], (size_t)qr * A->B.R, q0.hits,
-                                          nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
-        }
-        __syncthreads();
-        WF_TL(1);
-        int q = 0;
-        if (wf_args()->P.msaa > 1) {
-            {
-                const WfLaunchC A = wf_args();
-                const WfBuffers B = wf_ld(A->B);
-                wf_msaa_region(A->P, B, wf_ld(A->B.rays[0]), wf_ld(A->B.rays[1]), WF_SLOT0(A), A->rgb, A->depth, A->tri, A->centre_hit,
-                               A->ctr, qr, &sh);
-            }
+        // One call site for all stages: a single copy of the walks and of the shading code in the
+        // kernel (three specialised copies: 10.6 ms per 4K frame).
+        for (int stage = wf_args()->P.msaa > 1 ? 0 : 1; stage <= 6; ++stage) {
+            const int level = stage > 1 ? stage - 1 : 0; // stage 6 = level 5: only the shadow rays of level 4
+            if (stage > 1 && sh.child[level % 3] == 0 && sh.shd[(level + 2) % 3] == 0) break;
+            wf_stage<COUNT, SOFT>(stage == 0 ? WF_ST_CENTRE : (stage == 1 ? WF_ST_CAMERA : WF_ST_LEVEL), level, r, qr,
+                                  &sh, s_mem, st);
             __syncthreads();
-            q = 1;
-            {
-                const WfLaunchC A = wf_args();
-                const DScene    S = wf_ld(A->S);
-                const WfRays    q1 = wf_ld(A->B.rays[1]);
-                wf_trace_region<false, COUNT>(S, q1.o_w, q1.d_ni, mk3(0, 0, 0), q1.cnt[qr], (size_t)qr * A->B.R,
-                                              q1.hits, nullptr, wf_stack(S, s_mem), n_tests, n_nodes, n_closest);
-            }
-            __syncthreads();
-        }
-        WF_TL(2);
-        // level by level: shade(l) -> [shadow(l) + closest(l + 1)] -> resolve(l)
-        if (wf_args()->B.rays[q].cnt[qr] > 0) {
-            {
-                const WfLaunchC A = wf_args();
-                const WfBuffers B = wf_ld(A->B);
-                wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), wf_ld(A->B.rays[q ^ 1]), qr, &sh, n_shaded, n_child,
-                                      WF_SLOT0(A));
-            }
-            __syncthreads();
-            for (int level = 0; level < 5; ++level, q ^= 1) {
-                int n_out;
-                {
-                    const WfLaunchC A = wf_args();
-                    const DScene    S = wf_ld(A->S);
-                    const WfBuffers B = wf_ld(A->B);
-                    const WfRays    out = wf_ld(A->B.rays[q ^ 1]);
-                    n_out = out.cnt[qr];
-                    wf_trace_merged<COUNT, SOFT>(S, A->P, B, out, n_out, qr, wf_stack(S, s_mem), n_tests, n_nodes,
-                                                 n_closest, n_shadow);
-                }
-                __syncthreads();
-                WF_TL(3 + 2 * level);
-                {
-                    const WfLaunchC A = wf_args();
-                    const WfBuffers B = wf_ld(A->B);
-                    wf_resolve_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q]), qr);
-                }
-                if (n_out == 0) break;
-                __syncthreads(); // resolve still reads the queue the next shade writes its children to
-                {
-                    const WfLaunchC A = wf_args();
-                    const WfBuffers B = wf_ld(A->B);
-                    wf_shade_region<SOFT>(A->S, A->P, B, wf_ld(A->B.rays[q ^ 1]), wf_ld(A->B.rays[q]), qr, &sh, n_shaded,
-                                          n_child, WF_SLOT0(A));
-                }
-                __syncthreads();
-                WF_TL(4 + 2 * level);
-            }
-            __syncthreads();
+            WF_TL(1 + stage);
         }
         WF_TL(13);
         {
             const WfLaunchC A = wf_args();
             const WfBuffers B = wf_ld(A->B);
-            for (int j = threadIdx.x; j < B.S; j += WF_BLOCK) {
-                const int i = qr * B.S + j;
-                if (i < WF_N(A)) wf_finalize_slot(A->P, B, WF_SLOT0(A), i, A->centre_hit, A->rgb, A->depth, A->tri);
+            const int       msaa = A->P.msaa;
+            const long long slot_base = A->slot0 + (long long)r * B.S;
+            const WfAccL    acc = {(WfLdsSums)(s_mem + (size_t)A->S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES),
+                                   (unsigned)(B.S * msaa)};
+            const int       n_px = msaa > 1 ? sh.n_hit : min(B.S, A->n - r * B.S);
+            for (int j = threadIdx.x; j < n_px; j += WF_BLOCK) {
+                int slot = j, x = 0, y = 0;
+                if (msaa > 1) {
+                    const int2 e = B.hit_list[(size_t)qr * B.S + j];
+                    slot = e.x, x = e.y & 0xffff, y = e.y >> 16;
+                } else if (!slot_to_pixel(A->P, slot_base + slot, x, y)) continue;
+                wf_finalize_pixel(A->P, B, acc, (unsigned)(slot * msaa), (size_t)y * A->P.W + x,
+                                  ((size_t)qr * B.S + slot) * msaa, A->rgb, A->depth, A->tri);
+            }
+            if (threadIdx.x == 0) {
+                atomicAdd(&A->ctr->camera_rays, (unsigned long long)sh.n_cam);
+                atomicAdd(&A->ctr->rays_closest, (unsigned long long)sh.n_closest);
+                atomicAdd(&A->ctr->rays_shadow, (unsigned long long)sh.n_shadow);
             }
         }
         WF_TL(14);
     }
-#undef WF_SLOT0
-#undef WF_N
     DCounters* ctr = wf_args()->ctr;
     for (int s = 32; s > 0; s >>= 1) {
-        n_tests += __shfl_down(n_tests, s);
-        n_nodes += __shfl_down(n_nodes, s);
-        n_closest += __shfl_down(n_closest, s);
-        n_shadow += __shfl_down(n_shadow, s);
+        st.n_tests += __shfl_down(st.n_tests, s);
+        st.n_nodes += __shfl_down(st.n_nodes, s);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&ctr->tri_tests, (unsigned long long)n_tests);
-        atomicAdd(&ctr->node_visits, (unsigned long long)n_nodes);
-        atomicAdd(&ctr->rays_closest, (unsigned long long)n_closest);
-        atomicAdd(&ctr->rays_shadow, (unsigned long long)n_shadow);
-    }
-    if (COUNT) { // the timed variant leaves these two out
-        for (int s = 32; s > 0; s >>= 1) n_shaded += __shfl_down(n_shaded, s), n_child += __shfl_down(n_child, s);
+    if (COUNT) { // the timed variant leaves these out
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&ctr->shaded_hits, (unsigned long long)n_shaded);
-            atomicAdd(&ctr->child_rays, (unsigned long long)n_child);
+            atomicAdd(&ctr->tri_tests, (unsigned long long)st.n_tests);
+            atomicAdd(&ctr->node_visits, (unsigned long long)st.n_nodes);
+        }
+        for (int s = 32; s > 0; s >>= 1)
+            st.n_shaded += __shfl_down(st.n_shaded, s), st.n_child += __shfl_down(st.n_child, s);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctr->shaded_hits, (unsigned long long)st.n_shaded);
+            atomicAdd(&ctr->child_rays, (unsigned long long)st.n_child);
         }
     }
 }

@@ -70,3 +70,8 @@ idx = np.argsort(-dur)[:8]
 for i in idx:
     print(f"  long region: start {start[i]/1e3:.2f} ms, dur {dur[i]:.0f} us, stages " +
           " ".join(str(int((tl[i, c] - tl[i, 0]) / 100)) if tl[i, c] else "-" for c in range(1, 15)))
+# the regions that end last: what the tail of the launch consists of
+idx = np.argsort(-end)[:8]
+for i in idx:
+    print(f"  late region: start {start[i]/1e3:.2f} ms, end {end[i]/1e3:.2f} ms, dur {dur[i]:.0f} us, stages " +
+          " ".join(str(int((tl[i, c] - tl[i, 0]) / 100)) if tl[i, c] else "-" for c in range(1, 15)))
