@@ -382,7 +382,8 @@ struct WfRegion {
     ACC       acc;       // the colour sums, and
     unsigned  acc0;      // the region's first sample in them
     long long slot_base; // pixel slot of the region's first pixel slot
-    int       par;       // parity of the level being shaded (its shadow queue and records)
+    size_t    lvl0;      // first slot of the region in the buffers of the level being shaded (shadow queue and
+                         // records, kept per level parity): parity * cap + base
     int*      n_child;   // rays appended to the next level's queue
     int*      n_sh;      // shadow rays appended
 };
@@ -411,10 +412,10 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     const int      k = (int)((meta >> 16) & 7u);
     const unsigned route = (meta >> 19) & 0xffu;
     const size_t   sample = g.sample0 + sl;
-    unsigned char* rec = B.rec + ((size_t)g.par * B.cap + g.base + j) * B.rec_stride;
+    unsigned char* rec = B.rec + (g.lvl0 + j) * B.rec_stride;
     float*         rec_v = (float*)(rec + sizeof(WfRecord));
     const int      per = SOFT ? B.ns : 1;
-    const size_t   sq0 = ((size_t)g.par * B.cap + g.base) * L * per; // the region's shadow queue
+    const size_t   sq0 = g.lvl0 * L * per; // the region's shadow queue
     const bool is_hit = valid && got;
     bool       final_now = valid && !got;
     f3         colour = mk3(0, 0, 0);
@@ -848,7 +849,7 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level, long long slot0, DCounte
     unsigned       n_shaded = 0, n_child = 0;
     WfRegion<WfAcc> g;
     g.base = (size_t)r * B.R, g.sample0 = (size_t)r * B.S * P.msaa, g.slot_base = slot0 + (long long)r * B.S;
-    g.par = level & 1, g.n_child = &s_child, g.n_sh = &s_sh;
+    g.lvl0 = (size_t)(level & 1) * B.cap + g.base, g.n_child = &s_child, g.n_sh = &s_sh;
     g.acc.at = B.acc, g.acc.n = (unsigned)B.n_samples, g.acc0 = (unsigned)g.sample0;
     if (threadIdx.x == 0) s_child = 0, s_sh = 0;
     __syncthreads();
@@ -993,21 +994,29 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     WfRegion<WfAccL> g;
     g.base = (size_t)qr * B.R, g.sample0 = (size_t)qr * B.S * msaa;
     g.slot_base = A->slot0 + (long long)r * B.S;
-    g.par = level & 1, g.n_child = &sh->child[(level + 1) % 3], g.n_sh = &sh->shd[level % 3];
+    g.lvl0 = (size_t)__builtin_amdgcn_readfirstlane((level & 1) * B.cap) + g.base;
+    g.n_child = &sh->child[(level + 1) % 3], g.n_sh = &sh->shd[level % 3];
+    const size_t in0 = (size_t)__builtin_amdgcn_readfirstlane(((level + 1) & 1) * B.cap) + g.base; // the level before
+    const int    ms = msaa == 16 ? 4 : (msaa == 4 ? 2 : 0); // msaa is 1, 4 or 16
     g.acc.at = (WfLdsSums)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES); // after the stacks
     g.acc.n = (unsigned)(B.S * msaa), g.acc0 = 0;
+    // (what is read from LDS is the same for every lane; said so, it lives in scalar registers and
+    // not, as a vector register per value, in scratch during the walks)
     int n_first = B.S, n_sh = 0;
-    if (kind == WF_ST_CAMERA && msaa > 1) n_first = sh->n_hit * msaa;
-    if (kind == WF_ST_LEVEL) n_first = sh->child[level % 3], n_sh = sh->shd[(level + 2) % 3];
+    if (kind == WF_ST_CAMERA && msaa > 1) n_first = __builtin_amdgcn_readfirstlane(sh->n_hit) * msaa;
+    if (kind == WF_ST_LEVEL)
+        n_first = __builtin_amdgcn_readfirstlane(sh->child[level % 3]),
+        n_sh = __builtin_amdgcn_readfirstlane(sh->shd[(level + 2) % 3]);
     if (kind != WF_ST_CENTRE && threadIdx.x == 0) // the outputs of the stage after this one
         sh->child[(level + 2) % 3] = 0, sh->shd[(level + 1) % 3] = 0;
     const WfRays in = wf_ld(A->B.rays[level & 1]), out = wf_ld(A->B.rays[(level + 1) & 1]);
     const int    seg_c = (n_first + 63) & ~63;
     const int    total = seg_c + n_sh;
     const int    lane = threadIdx.x & 63;
-    const size_t sq_in = ((size_t)((level + 1) & 1) * B.cap + g.base) * P.n_lights * (SOFT ? B.ns : 1);
+    const size_t sq_in = in0 * P.n_lights * (SOFT ? B.ns : 1);
     for (int i0 = (int)threadIdx.x - lane; i0 < total; i0 += WF_BLOCK) {
-        const int idx = i0 + lane;
+        int idx = i0 + lane;
+        asm volatile("" : "+v"(idx)); // keeps per-lane addresses from being formed (and spilled) ahead of the loop
         if (i0 < seg_c) {
             // Before the walk only the ray itself is formed; whatever else the shading needs (weight,
             // prev_Ni, sample, queue addresses) is fetched or derived again afterwards from the
@@ -1023,9 +1032,9 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             } else {
                 int x = 0, y = 0, sn = -1;
                 if (kind == WF_ST_CAMERA && msaa > 1) { // pixel of a centre hit, as the centre stage left it
-                    xy = valid ? B.hit_list[(size_t)qr * B.S + idx / msaa].y : 0;
+                    xy = valid ? B.hit_list[(size_t)qr * B.S + (idx >> ms)].y : 0;
                     x = xy & 0xffff, y = xy >> 16;
-                    sn = idx % msaa;
+                    sn = idx & (msaa - 1);
                 } else {
                     valid = valid && idx < n_slots && slot_to_pixel(P, g.slot_base + idx, x, y);
                     xy = x | (y << 16);
@@ -1065,7 +1074,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                 unsigned meta = 0;
                 if (valid) {
                     if (kind == WF_ST_LEVEL) w = in.o_w[g.base + j].w, ni = in.d_ni[g.base + j].w, meta = in.meta[g.base + j];
-                    else if (msaa > 1) meta = wf_meta((unsigned)(B.hit_list[(size_t)qr * B.S + j / msaa].x * msaa + j % msaa), 0u, 0u);
+                    else if (msaa > 1) meta = wf_meta((unsigned)((B.hit_list[(size_t)qr * B.S + (j >> ms)].x << ms) + (j & (msaa - 1))), 0u, 0u);
                     else meta = wf_meta((unsigned)j, 0u, 0u);
                 }
                 wf_shade_ray<SOFT>(S, P, B, out, g, valid, j, o, dir, w, ni, meta, got, h.slot, h.a, h.b, h.t,
@@ -1083,7 +1092,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             HitRec h;
             if (idx == i0) atomicAdd(&sh->n_shadow, min(64, total - i0));
             const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, st.n_tests, st.n_nodes);
-            wf_shadow_done<SOFT>(P, B, (size_t)((level + 1) & 1) * B.cap + g.base + (__float_as_int(ow.w) & 0xffffff),
+            wf_shadow_done<SOFT>(P, B, in0 + (__float_as_int(ow.w) & 0xffffff),
                                  g.acc, g.acc0, li, got);
         }
     }
@@ -1109,7 +1118,7 @@ k_wf_pipeline(WfLaunch)
             sh.n_closest = 0, sh.n_shadow = 0;
         }
         __syncthreads();
-        const int r = sh.region;
+        const int r = __builtin_amdgcn_readfirstlane(sh.region);
         if (r >= wf_args()->n_regions) break;
         WF_TL(0);
 #ifdef WF_TIMELINE
@@ -1119,7 +1128,7 @@ k_wf_pipeline(WfLaunch)
         // kernel (three specialised copies: 10.6 ms per 4K frame).
         for (int stage = wf_args()->P.msaa > 1 ? 0 : 1; stage <= 6; ++stage) {
             const int level = stage > 1 ? stage - 1 : 0; // stage 6 = level 5: only the shadow rays of level 4
-            if (stage > 1 && sh.child[level % 3] == 0 && sh.shd[(level + 2) % 3] == 0) break;
+            if (stage > 1 && __builtin_amdgcn_readfirstlane(sh.child[level % 3] | sh.shd[(level + 2) % 3]) == 0) break;
             wf_stage<COUNT, SOFT>(stage == 0 ? WF_ST_CENTRE : (stage == 1 ? WF_ST_CAMERA : WF_ST_LEVEL), level, r, qr,
                                   &sh, s_mem, st);
             __syncthreads();
@@ -1133,7 +1142,7 @@ k_wf_pipeline(WfLaunch)
             const long long slot_base = A->slot0 + (long long)r * B.S;
             const WfAccL    acc = {(WfLdsSums)(s_mem + (size_t)A->S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES),
                                    (unsigned)(B.S * msaa)};
-            const int       n_px = msaa > 1 ? sh.n_hit : min(B.S, A->n - r * B.S);
+            const int       n_px = msaa > 1 ? __builtin_amdgcn_readfirstlane(sh.n_hit) : min(B.S, A->n - r * B.S);
             for (int j = threadIdx.x; j < n_px; j += WF_BLOCK) {
                 int slot = j, x = 0, y = 0;
                 if (msaa > 1) {
