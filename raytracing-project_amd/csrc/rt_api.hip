@@ -1648,6 +1648,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         auto kern = P.soft_n > 0 ? (count ? k_wf_pipeline<true, true> : k_wf_pipeline<false, true>)
                                  : (count ? k_wf_pipeline<true, false> : k_wf_pipeline<false, false>);
         WfLaunch A;
+        if (P.msaa > 1 || !d_tri) C[0].s_tri = nullptr; // nobody reads the samples' triangles then
         A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
         A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.ctr = s->d_ctr;
         hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), lds_single, st, A); // pl.G <= resident blocks

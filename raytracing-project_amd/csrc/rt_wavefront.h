@@ -112,7 +112,8 @@ struct WfBuffers {
     int*           prefix;    // multi-launch: [G + 1] for the ray queue, then [G + 1] for the shadow queue
     long long*     acc;       // [3][n_samples] fixed-point colour sums; the single launch keeps them in LDS instead
     float*         s_minT;    // per sample: t of the camera ray's hit (FLT_MAX = miss)
-    int*           s_tri;     // per sample: triangle of the camera ray's hit
+    int*           s_tri;     // per sample: triangle of the camera ray's hit (null when no caller reads it: MSAA > 1
+                              // takes the triangle of the pixel-centre ray, or no triangle plane is asked for)
     int2*          hit_list;  // k_wf_pipeline, MSAA > 1: [G * S] pixel slots whose centre ray hit: slot, x | y << 16
     WfCounters*    ctr;
     int            cap;       // slots of every queue = G * R
@@ -566,7 +567,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     if (valid) {
         if (k == 0) { // the camera ray fixes the sample's depth and triangle
             B.s_minT[sample] = ht;
-            B.s_tri[sample] = got ? orig : -1;
+            if (B.s_tri) B.s_tri[sample] = got ? orig : -1;
             wf_acc_set(g.acc, g.acc0 + sl, final_now ? colour : mk3(0, 0, 0));
         } else if (final_now) wf_acc_add(g.acc, g.acc0 + sl, colour);
     }
@@ -581,6 +582,12 @@ __device__ __forceinline__ unsigned wf_peek(const unsigned* p)
 // A shadow ray reports its answer.  The ray that brings the hit's count of pending queries to
 // zero knows every answer and finishes the light loop: raytracing.cpp:142-164 with the
 // queries answered.  rec: the hit's record; sample0: first sample of the hit's region.
+// An atomic on HBM is a transaction with the memory fabric on this hardware whatever scope it
+// asks for (36.7 M of them per 4K frame of final.obj, 1.2 GB written).  Tried instead and not
+// kept: one byte per light set by plain stores and a lane per record finishing the light loop in
+// the stage after (no atomics, but the records have left the L2 by then: 10.1 vs 9.7 ms, 14.4 vs
+// 13.8 GB); non-temporal loads and stores for the queue entries (10.4 ms, traffic unchanged);
+// colour sums and records as arrays of structures (atomics to three words of one line: 11.2 ms).
 template <bool SOFT, class PT, class ACC>
 __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, size_t slot, const ACC& acc,
                                                unsigned acc0, int li, bool occluded)
@@ -643,7 +650,7 @@ __device__ __forceinline__ void wf_finalize_pixel(const PT& P, const WfBuffers& 
         rgb[3 * p + 1] = wf_clamp01((float)((double)acc.at[acc.n + acc_i] / WF_FIX_SCALE));
         rgb[3 * p + 2] = wf_clamp01((float)((double)acc.at[2 * acc.n + acc_i] / WF_FIX_SCALE));
         depth[p] = B.s_minT[sample];
-        if (tri) tri[p] = B.s_tri[sample];
+        if (tri && B.s_tri) tri[p] = B.s_tri[sample];
         return;
     }
     float r = 0, g = 0, b = 0, dsum = 0;
@@ -904,7 +911,9 @@ k_wf_finalize(DParams P, WfBuffers B, long long slot0, int n, const unsigned cha
 // costs more than the shorter tail gains); units of 128/64/32/16 pixel slots handed out
 // coarse first (the chain of dependent stages does not get shorter with fewer rays, and
 // regions below 64 slots leave most of a block's waves empty: 16 slots 5.9 ms vs 2.6 ms for
-// an eighth of a 4K frame).
+// an eighth of a 4K frame; the same with the fused stages, only the last 10 / 25 / 50 % of the
+// slots in regions of half the size: 9.80 / 9.90 / 10.16 ms against 9.79, 2.02 / 2.01 / 2.06
+// against 2.04 ms for an eighth).
 // A block takes a region (one atomic), runs every stage of its pixels - centre rays and MSAA
 // gating, camera samples, five levels of child and shadow rays, pixel resolve - and takes the
 // next region.  Stages of a region are separated by block barriers only; there is no

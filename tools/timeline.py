@@ -50,11 +50,12 @@ busy = np.cumsum(ev[:, 1])
 for k in range(40):
     sel = (ev[:, 0] >= edges[k]) & (ev[:, 0] < edges[k + 1])
     print(f"  t={edges[k]/1e3:6.2f} ms  busy blocks ~{busy[sel].mean() if sel.any() else float('nan'):7.0f}  regions started {int(((start >= edges[k]) & (start < edges[k+1])).sum())}")
-# stage shares (per region: 0 start, 1 centre traced, 2 samples traced, 3+2l trace(l), 4+2l shade(l+1), 13 levels done, 14 end)
-names = ["gen+centre trace", "msaa emit+trace"] + [f"L{l} {s}" for l in range(5) for s in ("shade+trace", "resolve+shade")]
+# stage shares (per region: 0 start, 1 centre rays traced, 2 camera samples traced and shaded,
+# 2 + l: level l traced and shaded together with the shadow rays of level l - 1; 13 levels done, 14 end)
+names = ["centre rays", "camera samples (level 0)"] + [f"level {l} + shadows {l - 1}" for l in range(1, 6)]
 seg = np.zeros(len(names))
 prev = tl[:, 0].copy()
-cols = [1, 2] + [c for l in range(5) for c in (3 + 2 * l, 4 + 2 * l)]
+cols = [1, 2, 3, 4, 5, 6, 7]
 for i, c in enumerate(cols):
     cur = tl[:, c]
     ok = cur > 0
@@ -63,8 +64,8 @@ for i, c in enumerate(cols):
 tail = (tl[:, 14] - prev).sum()
 tot = seg.sum() + tail
 for n_, v in zip(names, seg):
-    print(f"  {n_:20s} {100*v/tot:5.1f}%")
-print(f"  {'last resolve+finalize':20s} {100*tail/tot:5.1f}%")
+    print(f"  {n_:26s} {100*v/tot:5.1f}%")
+print(f"  {'pixel resolve':26s} {100*tail/tot:5.1f}%")
 # the longest regions
 idx = np.argsort(-dur)[:8]
 for i in idx:
