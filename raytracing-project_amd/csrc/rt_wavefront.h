@@ -1067,7 +1067,11 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             HitRec   h;
             h.slot = -1, h.a = 0.0f, h.b = 0.0f, h.t = RT_FLT_MAX;
             bool got = false;
-            if (valid) got = wf_traverse<false, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
+            // The pixel-centre ray only decides whether the pixel's samples are traced (main.cpp:439-445); unless
+            // the caller wants its triangle, any hit answers that, and the walk ends at the first one.
+            if (kind == WF_ST_CENTRE && !A->tri) {
+                if (valid) got = wf_traverse<true, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
+            } else if (valid) got = wf_traverse<false, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
             int j = idx;
             asm volatile("" : "+v"(j)); // what follows is computed after the walk, not carried through it
             if (kind == WF_ST_CENTRE) { // misses are final pixels, hits queue their samples
