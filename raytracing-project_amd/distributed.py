@@ -27,7 +27,7 @@ def gather_frame(payload, W, H, tile_w, tile_h, rank, world, dist=None, unpack=N
     if world == 1:
         unpack(0, payload)
         return
-    if payload.shape[0] < max_slots:  # ranks differ by at most one tile
+    if payload.shape[0] < max_slots:  # gather wants equal sizes: pad to the largest rank's share (deals may be uneven)
         pad = torch.zeros((max_slots - payload.shape[0], 4), dtype=payload.dtype, device=payload.device)
         payload = torch.cat([payload, pad])
     payload = payload.contiguous()

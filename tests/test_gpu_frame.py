@@ -19,6 +19,13 @@ def P():
     return pkg()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _host_gpu(P, name):
     hs = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
     m, lights = P.host.read_camera_sav(os.path.join(SCENES, "cameras", name + ".sav"))
@@ -453,7 +460,7 @@ def test_bench_two_ranks_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_CHECK="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]

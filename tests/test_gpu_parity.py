@@ -249,3 +249,74 @@ def test_soft_shadows_match_oracle(oracle, name, n, msaa, W, H):
     p1.shadowSamples = 7
     with pytest.raises(capi.RtError, match="shadowSamples"):
         gs.trace_rays(o[:1], dd[:1], lights, params=p1)
+
+
+def _zoom_corners(eye, half, z_plane=0.0):
+    """The four corner rays of a camera at `eye` looking at the square [-half, half]^2 of the plane
+    z = z_plane, in the layout of RayTracer::raytrace (main.cpp:514-526): origin and destination of the
+    corners (0,0), (0,H-1), (W-1,0), (W-1,H-1)."""
+    c = []
+    for x, y in ((-half, half), (-half, -half), (half, half), (half, -half)):
+        c += list(eye) + [x, y, z_plane]
+    return np.float32(c)
+
+
+def test_distant_camera_matches_oracle(oracle):
+    """A camera a thousand mesh sizes away: the cell margins of the stack traversal are relative to
+    the ray parameter, whose rounding error grows with the distance of the origin.  The frame through
+    the wavefront pipeline still equals the oracle's: same triangles, colours within the 8-bit bar."""
+    s, g = _scene(oracle, "ball")
+    gs = gpu_scene_from_oracle(s)
+    W, H = 160, 160
+    for eye in ([0.3, 0.2, 1000.0], [900.0, -400.0, 300.0]):
+        corners = _zoom_corners(eye, 0.8)
+        s.settings.MSAA = 1
+        orgb, odepth, otri = s.render(corners, W, H, threads=8)
+        rgb, depth, tri, _ = gs.render(corners, g["lights"], pkg().capi.default_params(W, H, 1))
+        assert (otri >= 0).mean() > 0.05
+        assert (tri == otri).mean() >= 0.9999
+        same = (tri == otri) & (otri >= 0)
+        assert np.array_equal(depth[same], odepth[same])
+        diff = np.abs(oracle.to_bytes(rgb).astype(int) - oracle.to_bytes(orgb).astype(int)).max(axis=2)
+        assert (diff <= 1).mean() >= 0.999
+
+
+def test_equal_t_hits_in_different_leaves(oracle):
+    """Every triangle twice, at the same place: each hit is a tie between two triangles, and a
+    ray may meet the pair in leaves the two walks visit in a different order.  The reference keeps the
+    triangle its walk tests last (raytracing.cpp:323-349), the GPU the one with the larger rank
+    (breadth-first order of the reference's tree); for triangles on one root-to-leaf path these are the
+    same, across leaves they need not be.  What must hold: the same hit (t, hit point) bit for bit,
+    and the triangle is one of the twins."""
+    rng = np.random.default_rng(5)
+    n = 120
+    centre = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    v = (centre + 0.6 * rng.normal(size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    vpos = np.concatenate([v, v])
+    tri_v = np.arange(6 * n).reshape(-1, 3).astype(np.int32)
+    mats = np.zeros((1, 16), np.float32)
+    mats[0, :10] = [0.8, 0.3, 0.2, 0.5, 0.5, 0.5, 40, 1.0, 2, 1]
+    s = oracle.Scene.from_arrays(vpos, tri_v, np.zeros(2 * n, np.int32), mats)
+    gs = gpu_scene_from_oracle(s)
+    o = rng.uniform(-4, 4, (20000, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    tri, a, b, t, hp = gs.check_hits(o, d)
+    rtri, ra, rb, rt_, rhp = s.check_hits(o, d, threads=4)
+    hit = rtri >= 0
+    assert hit.mean() > 0.2 and np.array_equal(tri >= 0, hit)
+    assert np.array_equal(t[hit].view(np.uint32), rt_[hit].view(np.uint32))
+    assert np.array_equal(hp[hit].view(np.uint32), rhp[hit].view(np.uint32))
+    assert np.array_equal(tri[hit] % n, rtri[hit] % n)          # the same pair
+    agree = (tri[hit] == rtri[hit]).mean()
+    print(f"twin chosen as by the reference's walk: {agree:.4f}")
+    # the same scene as a frame through the wavefront pipeline
+    W, H = 96, 96
+    corners = _zoom_corners([0.0, 0.0, 9.0], 2.5)
+    s.set_lights(np.float32([[0, 0, 6]]))
+    s.settings.MSAA = 1
+    orgb, odepth, otri = s.render(corners, W, H, threads=8)
+    rgb, depth, ftri, _ = gs.render(corners, np.float32([[0, 0, 6]]), pkg().capi.default_params(W, H, 1))
+    both = (otri >= 0) & (ftri >= 0)
+    assert np.array_equal(otri >= 0, ftri >= 0)
+    assert np.array_equal(ftri[both] % n, otri[both] % n)
+    assert np.array_equal(depth[both], odepth[both])
