@@ -552,7 +552,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     }
     if (is_hit) {
         if (ncast == 0) { // no answer can change it: final
-            const float sm = T * __fdiv_rn(P.ShadowFactor, (float)L); // raytracing.cpp:102
+            const float sm = L > 0 ? T * __fdiv_rn(P.ShadowFactor, (float)L) : 0.0f; // raytracing.cpp:102; no light, no term
             colour = (C - mk3(sm, sm, sm)) * wl;
             final_now = true;
         } else {

@@ -320,3 +320,20 @@ def test_equal_t_hits_in_different_leaves(oracle):
     assert np.array_equal(otri >= 0, ftri >= 0)
     assert np.array_equal(ftri[both] % n, otri[both] % n)
     assert np.array_equal(depth[both], odepth[both])
+
+
+def test_frame_without_lights(oracle):
+    """No light at all: the ambient term alone (raytracing.cpp:92-95; the shadow share
+    ShadowFactor / 0 of raytracing.cpp:102 is never used)."""
+    s, g = _scene(oracle, "redballs")
+    s.set_lights(np.zeros((0, 3), np.float32))
+    gs = gpu_scene_from_oracle(s)
+    W, H = 96, 54
+    corners = oracle.camera_corners(g["modelview"], W, H)
+    s.settings.MSAA = 4
+    orgb, odepth, otri = s.render(corners, W, H, threads=8)
+    rgb, depth, tri, st = gs.render(corners, np.zeros((0, 3), np.float32), pkg().capi.default_params(W, H, 4))
+    assert np.isfinite(rgb).all() and st.rays_shadow == 0
+    assert (tri == otri).mean() >= 0.9999
+    diff = np.abs(oracle.to_bytes(rgb).astype(int) - oracle.to_bytes(orgb).astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
