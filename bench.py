@@ -28,7 +28,8 @@ After the timed loop, outside it, the last frame is checked: sparse pixels
 against the committed fixture of the CPU oracle, blurred pixels against the
 oracle's kernel; a mismatch fails the run ("checked" in the line).  On one GPU
 the line also carries a record per other BASELINE config ("configs"), the wall
-time of the drop-in 'r' path ("r_path_ms") and the CPU baseline.
+time of the drop-in 'r' path ("r_path_ms"), an eighth of the frame alone and with two frames in flight
+("frame_parts_in_flight": what a rank of eight GPUs would render) and the CPU baseline.
 """
 import argparse
 import importlib
@@ -125,6 +126,42 @@ def r_path_ms(pkg, dev_index):
                                  os.path.join(ROOT, "scenes", "cameras", SCENE + ".sav"), W, H, MSAA, tmp,
                                  dev_index, runs=2)
     return t
+
+
+def frame_parts_in_flight(pkg, hs, corners, lights, dev_index, parts=8, frames=32):
+    """What one rank of `parts` GPUs would render, measured on this GPU: its share of the tiles of the
+    headline frame, alone and with two such frames in flight on streams of their own (as the timed loop
+    keeps them with several GPUs).  Render only: no gather, no post-process."""
+    import torch
+    capi = pkg.capi
+    p = capi.default_params(W, H, MSAA)
+    p.tile_w = p.tile_h = TILE
+    p.world, p.rank = parts, 0
+    res = {"parts": parts, "what": f"rank 0's tiles of a {parts}-GPU deal rendered on one GPU, ms per frame part"}
+    dev = f"cuda:{dev_index}"
+    slots = [{"gs": hs.to_gpu(dev_index), "st": torch.cuda.Stream(),
+              "rgb": torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
+              "depth": torch.zeros((H, W), dtype=torch.float32, device=dev)} for _ in range(4)]
+
+    def go(which, n):
+        for i in range(n):
+            sl = slots[which[i % len(which)]]
+            sl["gs"].render_device(corners, lights, p, sl["rgb"].data_ptr(), sl["depth"].data_ptr(), 0,
+                                   sl["st"].cuda_stream, False)
+        torch.cuda.synchronize()
+
+    def ms(which):
+        go(which, 2 * len(which))
+        t0 = time.perf_counter()
+        go(which, frames)
+        return round((time.perf_counter() - t0) * 1e3 / frames, 3)
+
+    res["one_in_flight_ms"] = ms([0])
+    # whether two launches overlap depends on the hardware queues their streams were given: try the pairs
+    pairs = {f"0+{k}": ms([0, k]) for k in (1, 2, 3)}
+    res["two_in_flight_ms"] = min(pairs.values())
+    res["pairs"] = pairs
+    return res
 
 
 def executed_flop(st, n_lights):
@@ -274,9 +311,13 @@ def main():
     # frame i retire, and on rank 0 the post-process of frame i overlaps the render of i + 1.
     # On one GPU the frames run one after the other, so that the launch durations behind the
     # roofline figure are those of a launch that has the GPU to itself.
+    # Whether two launches really overlap depends on the hardware queues the runtime gave their streams
+    # (not visible to a program): with two frames in flight, four candidates are made and, once the
+    # deal is settled, the partner of the first is the one whose launches are seen to overlap its own.
     n_flight = args.frames_in_flight or (1 if world == 1 else 2)
+    n_cand = 4 if n_flight == 2 else n_flight
     slots = []
-    for i in range(n_flight):
+    for i in range(n_cand):
         st_ = torch.cuda.Stream(device=dev) if n_flight > 1 else torch.cuda.current_stream()
         slots.append({"gs": hs.to_gpu(local), "stream": st_,
                       "rgb": torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
@@ -435,6 +476,26 @@ def main():
         same = bcast_int(same)
         state["gather"] = "rt_gather_tiles_rccl" if same else \
             "torch.distributed.gather (rt_gather_tiles_rccl rebuilt a different frame)"
+
+    flight_probe = None
+    if n_cand > n_flight:
+        def part_ms(which, n=12):
+            for rep_ in range(2):                       # the first pass warms up
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for i in range(n):
+                    sl = slots[which[i % len(which)]]
+                    sl["gs"].render_device(corners, lights, p, sl["rgb"].data_ptr(), sl["depth"].data_ptr(), 0,
+                                           sl["stream"].cuda_stream, False)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t_) * 1e3 / n
+        alone = part_ms([0])
+        pairs = {k: part_ms([0, k]) for k in range(1, n_cand)}
+        best = min(pairs, key=pairs.get)
+        flight_probe = {"render_alone_ms": round(alone, 3),
+                        "with_partner_ms": {str(k): round(v, 3) for k, v in pairs.items()}, "partner": best}
+        slots = [slots[0], slots[best]]                 # the others' buffers are released with them
+        torch.cuda.empty_cache()
 
     # one counted frame: rays this rank traces per frame (deterministic)
     st = frame(0, stats=True)
@@ -595,6 +656,8 @@ def main():
         if n_flight == 1:
             out["kernel_ms"]["dof_and_gather"] = round(ms - kt.frame_ms / max(kt.frames, 1), 3)
         out["config"]["frames_in_flight"] = n_flight
+        if flight_probe:
+            out["config"]["frames_in_flight_probe"] = flight_probe
         info = gs.info()
         out["scene_create_ms"] = {"rt_scene_create": round(info["create_ms"], 2),
                                   "tree_hand_down_and_refine": round(info["tree_ms"], 2),
@@ -604,6 +667,7 @@ def main():
             out["configs"] = {f"{n_}_{w_}x{h_}_msaa{m_}": config_record(pkg, n_, w_, h_, m_, fc_all, local)
                               for n_, w_, h_, m_ in OTHER_CONFIGS}
             out["r_path_ms"] = r_path_ms(pkg, local)
+            out["frame_parts_in_flight"] = frame_parts_in_flight(pkg, hs, corners, lights, local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)
         print(json.dumps(out), flush=True)
