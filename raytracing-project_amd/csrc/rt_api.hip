@@ -1570,11 +1570,12 @@ static void wf_launch_trace(RtScene* s, const WfBuffers& C, int q, int msaa, int
     timing_end(s, te, st);
 }
 
-// One frame part (the pixel slots [0, n_slots) of this rank).  The slots are cut into
-// chunks that fit the workspace.  RT_WF_PIPES > 1 puts that many chunks in flight on
-// streams of their own; measured on MI355X this is slower than one chunk after the
-// other (8 GPUs' share of a 4K frame: 7.8 ms with 1 pipeline, 8.6 / 9.9 / 12.5 ms with
-// 2 / 3 / 4), so the default is 1.
+// One frame part (the pixel slots [0, n_slots) of this rank).  The product path is one persistent
+// launch over one set of buffers per resident block, whatever the size of the frame.  With
+// RT_WF_MULTILAUNCH=1 the slots are cut into chunks that fit the workspace (a set of buffers per
+// region) and every stage is a launch of its own; RT_WF_PIPES > 1 then puts that many chunks in
+// flight on streams of their own (measured slower than one chunk after the other, so the
+// default is 1).
 static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, float* d_rgb, float* d_depth,
                             int32_t* d_tri, hipStream_t user, bool count)
 {
@@ -1591,8 +1592,8 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     if (!single && P.soft_n > 0)
         return fail(RT_ERR_UNSUPPORTED, "soft shadows are not available with RT_WF_MULTILAUNCH=1");
     int        S = 512;
-    if (single) { // measured on a 4K MSAA4 frame: 128 slots for the whole frame (12.3 ms; 256: 12.6, 64: 13.5),
-                  // 64 for an eighth of it (2.6 ms; 128: 3.0)
+    if (single) { // measured on a 4K MSAA4 frame: 128 slots for the whole frame (9.7 ms; 192: 10.9, 64: 11.7),
+                  // 64 for an eighth of it (2.0 ms; 128: 2.8)
         const long long per_block = n_slots / (16LL * std::max(s->wf_grid_pipe, 1));
         S = per_block >= 512 ? 256 : (per_block >= 100 ? 128 : 64);
     }
