@@ -627,6 +627,10 @@ def main():
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "frac_reference_walk": round(
                             fc["flops_frame"] * frac0 / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        "frac_reference_walk_note": "the reference's whole walk (F of the survey, 105 tests per ray "
+                        "in its tree) priced at this launch's duration: a yardstick of the frame against the "
+                        "reference's algorithm, above 1 once the launch is faster than a peak-rate machine running "
+                        "that algorithm; the launch itself executes the work under 'executed'",
                         "executed": {"gflop_per_launch": round(exe / 1e9, 2),
                                      "achieved": round(exe / (kern_ms * 1e-3) / 1e12, 3),
                                      "frac": round(exe / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
