@@ -1312,6 +1312,16 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
     st->camera_rays = c.camera_rays;
     st->shaded_hits = c.shaded_hits;
     st->child_rays = c.child_rays;
+#ifdef WF_DIAG
+    {
+        unsigned long long d[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_diag), sizeof d);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
+        fprintf(stderr, "diag: node loop lanes %.4f (%llu of %llu), triangle loop lanes %.4f (%llu of %llu)\n",
+                (double)c.node_visits / (double)(d[0] ? d[0] : 1), (unsigned long long)c.node_visits, d[0],
+                (double)c.tri_tests / (double)(d[1] ? d[1] : 1), (unsigned long long)c.tri_tests, d[1]);
+    }
+#endif
     float ms = 0;
     (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
     st->kernel_ms = ms;

@@ -220,6 +220,12 @@ __device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
 // ray) with all results unchanged, and made the frame slower (12.6 vs 12.05 ms): the extra
 // load per test costs more than the arithmetic it saves, and a large triangle no longer sets
 // the closest hit early from a distant cell (6 % more node steps).
+#ifdef WF_DIAG
+// Diagnostic builds only (-DWF_DIAG): lane slots (wave trips x 64) of the node loop and of the triangle
+// loop of the counted launch; rt_api.hip prints them against the lanes that did work (final.obj 4K MSAA4:
+// 94 % in the node loop, 69 % in the triangle loop).
+__device__ unsigned long long g_diag[4];
+#endif
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
@@ -240,6 +246,9 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         uint2 nd = S.knodes[node];
         if (COUNT) ++n_nodes;
         while ((nd.y >> 30) != 3u) {
+#ifdef WF_DIAG
+            if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
+#endif
             const unsigned axis = nd.y >> 30;
             const int      left = (int)(nd.y & 0x3fffffffu);
             const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
@@ -268,6 +277,9 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
             float        a, b, t;
             if (COUNT) ++n_tests;
+#ifdef WF_DIAG
+            if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
+#endif
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
