@@ -1606,6 +1606,9 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                   // 64 for an eighth of it (2.0 ms; 128: 2.8)
         const long long per_block = n_slots / (16LL * std::max(s->wf_grid_pipe, 1));
         S = per_block >= 512 ? 256 : (per_block >= 100 ? 128 : 64);
+        // without MSAA a region of 64 slots is one wave of camera rays for a block of four
+        // (1080p: redballs 3.03 -> 2.59 ms, refractionballs 3.59 -> 2.77 ms with 128)
+        if (P.msaa == 1) S = std::max(S, 128);
     }
     if (s->cfg.region > 0) S = s->cfg.region;
     S = std::max(64, std::min(4096, (S / 64) * 64));
