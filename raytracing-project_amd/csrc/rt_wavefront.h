@@ -332,7 +332,18 @@ __device__ __forceinline__ int wf_append(int* lds_counter, bool mine, int per = 
     return mine ? base + __popcll(m & ((1ull << lane) - 1ull)) * per : -1;
 }
 
-__device__ __forceinline__ long long wf_fix(float v) { return (long long)llrint((double)v * WF_FIX_SCALE); }
+// v in units of 2^-32, rounded to nearest even: llrint((double)v * 2^32) without the double arithmetic
+// and the emulated 64-bit conversion.  For a = |v|, floor(a) and a - floor(a) are exact in float, and so
+// is the fraction times 2^32; only that product can have a part below one unit, which rintf rounds
+// as llrint would, and rounding to even is symmetric in the sign.  (|v| < 2^31; colour terms are of
+// the order of 1.)
+__device__ __forceinline__ long long wf_fix(float v)
+{
+    const float     a = fabsf(v), fl = floorf(a);
+    const unsigned  lo = (unsigned)rintf((a - fl) * 4294967296.0f);
+    const long long m = (long long)(((unsigned long long)(unsigned)fl << 32) | lo);
+    return v < 0.0f ? -m : m;
+}
 
 // Where the colour sums of the region being worked on are: three planes of `n` 64-bit sums,
 // `at[sample]` the first.  The single launch keeps them in LDS (a region belongs to one block, and
