@@ -1320,6 +1320,7 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
         fprintf(stderr, "diag: node loop lanes %.4f (%llu of %llu), triangle loop lanes %.4f (%llu of %llu)\n",
                 (double)c.node_visits / (double)(d[0] ? d[0] : 1), (unsigned long long)c.node_visits, d[0],
                 (double)c.tri_tests / (double)(d[1] ? d[1] : 1), (unsigned long long)c.tri_tests, d[1]);
+        fprintf(stderr, "diag: leaf visits: %llu empty, %llu with triangles\n", d[2], d[3]);
     }
 #endif
     float ms = 0;

@@ -276,6 +276,9 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
         const int first = (int)nd.x;
+#ifdef WF_DIAG
+        if (COUNT) atomicAdd(&g_diag[cnt == 0 ? 2 : 3], 1ull);
+#endif
         for (int i = 0; i < cnt; ++i) {
             const int    slot = first + i;
             const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
