@@ -260,6 +260,10 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #endif
             const unsigned axis = nd.y >> 30;
             const int      left = (int)(nd.y & 0x3fffffffu);
+            // Both children lie side by side: their records are asked for before the plane decides which
+            // one the walk takes, so the decision is made while the load is under way and the chain
+            // from node to node is the load alone.
+            const uint2 c0 = S.knodes[left], c1 = S.knodes[left + 1];
             const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
             const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
             const float    tplane = __builtin_fmaf(__uint_as_float(nd.x), ia, -oi);
@@ -276,7 +280,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 node = near;
                 tmax_e = tplane * (1.0f + RT_TRAV_EPS);
             }
-            nd = S.knodes[node];
+            nd = node == left ? c0 : c1;
             if (COUNT) ++n_nodes;
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
