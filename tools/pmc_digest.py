@@ -17,8 +17,9 @@ out = {"kernel": "k_wf_pipeline<false, false>, final.obj 3840x2160 MSAA4, one la
 g = vals.get
 if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
     out["lanes_active_in_valu"] = round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)
-if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CYCLES"):
-    out["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") / 4.0 / g("SQ_BUSY_CYCLES"), 4) if False else None
+if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+    # a wave instruction occupies its SIMD for 4 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs in all
+    out["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0), 4)
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     rd, wr = g("FETCH_SIZE") * 1024.0, g("WRITE_SIZE") * 1024.0
     out["hbm_bytes_per_launch"] = {"read_raw": rd, "read_corrected_x2": 2 * rd, "write": wr, "total_corrected": 2 * rd + wr,
