@@ -188,7 +188,11 @@ struct HitRec {
 // to the second, 21 % to the third, 10 % to the divisions; per wave (a stage runs when any
 // lane needs it) the figures are 60 % / 26 % / 13 %.  Testing two triangles per call with
 // packed FP32 arithmetic was tried and is slower (13.6-15.6 vs 12.7 ms per frame): the pair
-// needs twice the registers and survives a stage whenever either triangle does.
+// needs twice the registers and survives a stage whenever either triangle does.  Packing within one
+// test - D with the numerator of a, the numerator of b with that of t, term by term, v_pk_mul_f32 /
+// v_pk_add_f32 being separately rounded like the scalar forms - halves the arithmetic instructions and
+// keeps every bit, but the operands have to sit in aligned register pairs: 92 instead of 48 bytes of
+// scratch per lane under the 72-register cap, 9.7-9.8 vs 9.2 ms per 4K frame.
 __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, f3 o,
                                          f3 d, float minT, float& a, float& b, float& t)
 {
