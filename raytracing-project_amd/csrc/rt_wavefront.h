@@ -397,6 +397,17 @@ struct WfSurf {
     int4  info;
 };
 
+// Unit vector with the hardware's reciprocal square root (1 ulp) for the two directions that only enter
+// the specular term - towards the viewer and the halfway vector (raytracing.cpp:99, 131-132); the normal
+// and the light direction, which place rays, keep the reference's sqrt and division (normalize3).
+__device__ __forceinline__ void wf_unit(f3& a)
+{
+    const float l2 = dot3(a, a);
+    if (l2 == 0.0f) return;
+    const float r = __builtin_amdgcn_rsqf(l2);
+    a.x *= r, a.y *= r, a.z *= r;
+}
+
 __device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dir, int orig, float a, float b, float t,
                                            WfSurf& s)
 {
@@ -411,7 +422,7 @@ __device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dir, int or
     s.N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
     normalize3(s.N);
     s.viewDir = o - s.hp;
-    normalize3(s.viewDir);
+    wf_unit(s.viewDir);
 }
 
 // The specular power (raytracing.cpp:134): 0 < x <= 1 to the material's hardness, as 2^(n log2 x) with the
@@ -422,6 +433,7 @@ __device__ __forceinline__ float wf_pow(float x, float n)
 {
     return __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x));
 }
+
 
 // Where the data of the region being worked on lie, and the counters its stage appends with.
 template <class ACC>
@@ -566,7 +578,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
             if (v >= 0.0f) shadowMax = v;
             if (angle > 0.0f) {
                 f3 halfway = lightDir + s.viewDir;
-                normalize3(halfway);
+                wf_unit(halfway);
                 const float ah = dot3(s.N, halfway);
                 if (ah > 0.0f) C = C + s.Ks * wf_pow(ah, s.Ns);
                 // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
