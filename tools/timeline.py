@@ -33,10 +33,13 @@ kt = gs.collect_timing()
 NR = 140000
 tl = np.zeros((NR, 16), np.uint64)
 L.rt_debug_timeline(tl.ctypes.data, NR, 0)
-tl = tl[tl[:, 14] > 0].astype(np.int64)
+L_keep = tl[:, 14] > 0
+tl = tl[L_keep].astype(np.int64)
 t0 = tl[:, 0].min()
 start, end = (tl[:, 0] - t0) / 100.0, (tl[:, 14] - t0) / 100.0      # microseconds
 dur = end - start
+if os.environ.get("TL_DUMP"):  # region id order: row i of tl is not region i once empty rows are dropped
+    full = np.zeros(NR); ids = np.nonzero(np.asarray(L_keep))[0]; full[ids] = dur; np.save(os.environ["TL_DUMP"], full[: ids.max() + 1])
 total = end.max()
 print(f"{name} {W}x{H} msaa{msaa} world {p.world}: launch {kt.frame_ms:.3f} ms; {len(tl)} regions, "
       f"{len(np.unique(tl[:, 15]))} blocks, span {total/1e3:.3f} ms")
