@@ -29,7 +29,8 @@ against the committed fixture of the CPU oracle, blurred pixels against the
 oracle's kernel; a mismatch fails the run ("checked" in the line).  On one GPU
 the line also carries a record per other BASELINE config ("configs"), the wall
 time of the drop-in 'r' path ("r_path_ms"), an eighth of the frame alone and with two frames in flight
-("frame_parts_in_flight": what a rank of eight GPUs would render) and the CPU baseline.
+("frame_parts_in_flight": what a rank of eight GPUs would render; "whole_frames_in_flight": the
+throughput of this GPU with two whole frames in flight) and the CPU baseline.
 """
 import argparse
 import importlib
@@ -137,7 +138,9 @@ def frame_parts_in_flight(pkg, hs, corners, lights, dev_index, parts=8, frames=3
     p = capi.default_params(W, H, MSAA)
     p.tile_w = p.tile_h = TILE
     p.world, p.rank = parts, 0
-    res = {"parts": parts, "what": f"rank 0's tiles of a {parts}-GPU deal rendered on one GPU, ms per frame part"}
+    res = {"parts": parts, "what": f"rank 0's tiles of a {parts}-GPU deal rendered on one GPU, ms per frame part"
+                                   if parts > 1 else "the whole frame, render only, ms per frame: one after the other "
+                                   "and with two in flight (throughput; the timed loop on one GPU keeps one in flight)"}
     dev = f"cuda:{dev_index}"
     slots = [{"gs": hs.to_gpu(dev_index), "st": torch.cuda.Stream(),
               "rgb": torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
@@ -672,6 +675,7 @@ def main():
                               for n_, w_, h_, m_ in OTHER_CONFIGS}
             out["r_path_ms"] = r_path_ms(pkg, local)
             out["frame_parts_in_flight"] = frame_parts_in_flight(pkg, hs, corners, lights, local)
+            out["whole_frames_in_flight"] = frame_parts_in_flight(pkg, hs, corners, lights, local, parts=1, frames=16)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)
         print(json.dumps(out), flush=True)
