@@ -1,8 +1,7 @@
 // gpu_bridge.cpp - the file a maintainer of the reference would add to bind its host code to
 // librt_hip.so (include/rt_hip.h).  It is written against the reference's own headers and is
 // compiled, syntax only, by `make -C oracle ref` where the reference checkout is present, so
-// that the binding shown in INTEGRATION.md is known to fit raytracing.h / mesh.h / KDtree.h as
-// they are.  Nothing else in this repository uses it.
+// that this binding is known to fit raytracing.h / mesh.h / KDtree.h as they are.  Nothing else in this repository uses it.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -1,7 +1,7 @@
 """ctypes view of the C ABI declared in include/rt_hip.h (librt_hip.so).
 
 Plumbing for tests and bench.py only: the product is the shared library; a
-C++ host links to it directly (see INTEGRATION.md).
+C++ host links to it directly.
 """
 import ctypes as C
 import os

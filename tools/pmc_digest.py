@@ -1,6 +1,6 @@
 """Digest of the PMC passes tools/profile_round.sh leaves in a directory: per launch of the
 timed pipeline kernel (k_wf_pipeline<false, false>), counters averaged over its launches, plus
-the derived figures DESIGN.md quotes (lanes active, VALU busy, HBM traffic with the gfx950
+the derived figures the design notes quote (lanes active, VALU busy, HBM traffic with the gfx950
 correction of the FETCH_SIZE counter, cache hit rates)."""
 import csv, glob, json, os, sys
 d = sys.argv[1]
