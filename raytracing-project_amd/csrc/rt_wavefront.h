@@ -395,6 +395,7 @@ struct WfSurf {
     float Ns, Ni;
     int   illum, has_Ni, tex;
     int4  info;
+    bool  spec; // Ks != 0: with Ks = 0 the specular term adds +0 to a colour that is never -0, i.e. nothing
 };
 
 // Unit vector with the hardware's reciprocal square root (1 ulp) for the two directions that only enter
@@ -421,8 +422,9 @@ __device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dir, int or
     const float u = a, v = b, w = 1.0f - u - v;
     s.N = (mk3(s0.x, s0.y, s0.z) * u + mk3(s1.x, s1.y, s1.z) * v) + mk3(s2.x, s2.y, s2.z) * w;
     normalize3(s.N);
+    s.spec = s.Ks.x != 0.0f || s.Ks.y != 0.0f || s.Ks.z != 0.0f;
     s.viewDir = o - s.hp;
-    wf_unit(s.viewDir);
+    if (s.spec) wf_unit(s.viewDir);
 }
 
 // The specular power (raytracing.cpp:134): 0 < x <= 1 to the material's hardness, as 2^(n log2 x) with the
@@ -577,10 +579,12 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
             }
             if (v >= 0.0f) shadowMax = v;
             if (angle > 0.0f) {
-                f3 halfway = lightDir + s.viewDir;
-                wf_unit(halfway);
-                const float ah = dot3(s.N, halfway);
-                if (ah > 0.0f) C = C + s.Ks * wf_pow(ah, s.Ns);
+                if (s.spec) { // (a wave on a wall without highlights skips the block: walls are large)
+                    f3 halfway = lightDir + s.viewDir;
+                    wf_unit(halfway);
+                    const float ah = dot3(s.N, halfway);
+                    if (ah > 0.0f) C = C + s.Ks * wf_pow(ah, s.Ns);
+                }
                 // An occluded light can only raise shadowMax to 1 (raytracing.cpp:142-143).  Here
                 // shadowMax is its value with every query so far answered "free"; if that is 1
                 // already - set by a grazing angle at this light, or carried from an earlier one -
