@@ -1314,13 +1314,14 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
     st->child_rays = c.child_rays;
 #ifdef WF_DIAG
     {
-        unsigned long long d[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+        unsigned long long d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_diag), sizeof d);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
         fprintf(stderr, "diag: node loop lanes %.4f (%llu of %llu), triangle loop lanes %.4f (%llu of %llu)\n",
                 (double)c.node_visits / (double)(d[0] ? d[0] : 1), (unsigned long long)c.node_visits, d[0],
                 (double)c.tri_tests / (double)(d[1] ? d[1] : 1), (unsigned long long)c.tri_tests, d[1]);
         fprintf(stderr, "diag: leaf visits: %llu empty, %llu with triangles\n", d[2], d[3]);
+        fprintf(stderr, "diag: shadow rays %llu, occluded %llu, their tests %llu and node steps %llu\n", d[4], d[5], d[6], d[7]);
     }
 #endif
     float ms = 0;

@@ -233,7 +233,7 @@ __device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
 // Diagnostic builds only (-DWF_DIAG): lane slots (wave trips x 64) of the node loop and of the triangle
 // loop of the counted launch; rt_api.hip prints them against the lanes that did work (final.obj 4K MSAA4:
 // 94 % in the node loop, 69 % in the triangle loop).
-__device__ unsigned long long g_diag[4];
+__device__ unsigned long long g_diag[8]; // [4..7]: shadow rays traced / occluded, their triangle tests / node steps
 #endif
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
@@ -1168,7 +1168,16 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             }
             HitRec h;
             if (idx == i0) atomicAdd(&sh->n_shadow, min(64, total - i0));
+#ifdef WF_DIAG
+            const unsigned t0_ = st.n_tests, n0_ = st.n_nodes;
+#endif
             const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, st.n_tests, st.n_nodes);
+#ifdef WF_DIAG
+            if (COUNT) {
+                atomicAdd(&g_diag[4], 1ull), atomicAdd(&g_diag[5], got ? 1ull : 0ull);
+                atomicAdd(&g_diag[6], (unsigned long long)(st.n_tests - t0_)), atomicAdd(&g_diag[7], (unsigned long long)(st.n_nodes - n0_));
+            }
+#endif
             wf_shadow_done<SOFT>(P, B, in0 + (__float_as_int(ow.w) & 0xffffff),
                                  g.acc, g.acc0, li, got);
         }
