@@ -433,7 +433,8 @@ __device__ __forceinline__ void wf_surface(const DScene& S, f3 o, f3 dir, int or
 // against some hundred instructions for the library's powf, two of them per hit and light.
 __device__ __forceinline__ float wf_pow(float x, float n)
 {
-    return __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x));
+    // (the hardware's log2 of a denormal is -inf; times a hardness of 0 that would be NaN where powf gives 1)
+    return n == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x));
 }
 
 

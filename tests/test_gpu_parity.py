@@ -166,7 +166,7 @@ def test_random_scenes_match_oracle(oracle, seed):
     mats[0, :10] = [0.8, 0.3, 0.2, 0.5, 0.5, 0.5, 40, 1.0, 2, 1]      # diffuse
     mats[1, :10] = [0.2, 0.2, 0.9, 1.0, 1.0, 1.0, 96, 1.0, 3, 1]      # mirror
     mats[2, :10] = [0.9, 0.9, 0.9, 0.3, 0.3, 0.3, 20, 1.3, 2, 1]      # refractive
-    mats[3, :10] = [0.3, 0.8, 0.3, 0.0, 0.0, 0.0, 5, 1.0, 2, 0]       # diffuse, no Ni line
+    mats[3, :10] = [0.3, 0.8, 0.3, 0.2, 0.2, 0.2, 0, 1.0, 2, 0]       # no Ni line, hardness 0: the specular power is 1
     tri_mat = np.concatenate([rng.integers(0, 4, n_tri), [0, 3]]).astype(np.int32)
     s = oracle.Scene.from_arrays(vpos, tri_v, tri_mat, mats)
     lights = np.float32([[0, 0, 6], [4, -3, 5], [-5, 2, 1], [1, 5, -1]])
