@@ -70,6 +70,7 @@ struct WfShared {
     int n_cam;    // camera rays generated (statistics)
     int n_closest, n_shadow; // rays traced (statistics; counted per wave here, not in a register per lane)
     int region;   // k_wf_pipeline: the region the block works on
+    int batch[2]; // k_wf_pipeline: next 64 rays of the stage to hand to a wave (stages alternate between the two)
 };
 
 // One level's rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
@@ -1083,12 +1084,20 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
         n_sh = __builtin_amdgcn_readfirstlane(sh->shd[(level + 2) % 3]);
     if (kind != WF_ST_CENTRE && threadIdx.x == 0) // the outputs of the stage after this one
         sh->child[(level + 2) % 3] = 0, sh->shd[(level + 1) % 3] = 0;
+    const int par = kind == WF_ST_CENTRE ? 1 : (level & 1); // centre 1, camera 0, level l: l & 1
+    if (threadIdx.x == 0) sh->batch[par ^ 1] = 0;             // the stage after this one counts from 0
     const WfRays in = wf_ld(A->B.rays[level & 1]), out = wf_ld(A->B.rays[(level + 1) & 1]);
     const int    seg_c = (n_first + 63) & ~63;
     const int    total = seg_c + n_sh;
     const int    lane = threadIdx.x & 63;
     const size_t sq_in = in0 * P.n_lights * (SOFT ? B.ns : 1);
-    for (int i0 = (int)threadIdx.x - lane; i0 < total; i0 += WF_BLOCK) {
+    // A wave takes the next 64 rays when it is through with the last: the walks of a mirror corridor are
+    // ten times as long as those next to them, and with a fixed share per wave three waves wait for the fourth.
+    for (;;) {
+        int i0 = 0;
+        if (lane == 0) i0 = atomicAdd(&sh->batch[par], 1) * 64;
+        i0 = __builtin_amdgcn_readfirstlane(i0);
+        if (i0 >= total) break;
         int idx = i0 + lane;
         asm volatile("" : "+v"(idx)); // keeps per-lane addresses from being formed (and spilled) ahead of the loop
         if (i0 < seg_c) {
@@ -1202,6 +1211,7 @@ k_wf_pipeline(WfLaunch)
         if (threadIdx.x == 0) {
             sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
             sh.child[1] = 0, sh.shd[0] = 0, sh.n_hit = 0, sh.n_cam = 0; // what the camera stage appends to
+            sh.batch[0] = 0, sh.batch[1] = 0;
             sh.n_closest = 0, sh.n_shadow = 0;
         }
         __syncthreads();
