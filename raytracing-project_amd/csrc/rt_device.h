@@ -247,6 +247,64 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
 }
 
+// The same test for a walk that knows which stretch [lo, hi] of the ray lies in the cell it is in
+// (margins included).  The walk visits the cells along the ray front to back and every cell lists every
+// triangle that reaches into it, so a triangle whose plane the ray crosses before lo has been met - and
+// tested - in an earlier cell, and one crossed after hi will be met in a later one unless a nearer hit
+// ends the walk first: either way it can be dropped here as soon as D and the numerator of t say so.
+// final.obj, 4K MSAA4: of 1.44 G tests 33 % cross behind the origin, 15 % before the cell, 27 % beyond
+// it and 6 % beyond the closest hit so far; 19 % cross inside the cell.  So t goes first (it went last
+// in tri_test, where only t < 0 and t > minT can be told) and the numerators of a and b are evaluated
+// for a fifth of the tests.  An any-hit walk passes hi = FLT_MAX: a hit beyond the cell ends it.
+__device__ __forceinline__ bool tri_test_cell(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d,
+                                              float minT, float lo, float hi, float& a, float& b, float& t)
+{
+    const float e1x = q0.x, e1y = q0.y, e1z = q0.z, e2x = q0.w, e2y = q1.x, e2z = q1.y;
+    const float cx = o.x - q1.z, cy = o.y - q1.w, cz = o.z - q2.x;
+    const float p1 = q2.y, p4 = q2.z; // e1x*e2y, e1z*e2y
+    const float e2x_dy = e2x * d.y, dx_e1y = d.x * e1y, e2z_dy = e2z * d.y, dz_e1y = d.z * e1y;
+    const float D = p1 * d.z + e2x_dy * e1z + dx_e1y * e2z - p4 * d.x - e2z_dy * e1x - dz_e1y * e2x;
+    const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
+                     (cz * e1y) * e2x;
+    // |D| in [2^-40, 2^40] and |numerator| >= 2^-80 keep every quotient below clear of underflow
+    const float aD = fabsf(D);
+    const bool  Dok = aD >= 9.094947e-13f && aD <= 1.0995116e12f;
+    const float tiny = 8.271806e-25f; // 2^-80
+    const float aDm = aD * 1.00001f;  // |n| > bound * aDm  =>  |n / D| > bound after rounding
+    const int   sD = __float_as_int(D);
+    if (Dok) {
+        const float adt = fabsf(dt);
+        if (adt >= tiny) {
+            if ((__float_as_int(dt) ^ sD) >= 0) return false; // dt / D > 0, i.e. t = -(dt / D) < 0
+            if (adt > hi * aDm) return false;                 // t > hi (hi <= minT)
+            if (adt * 1.00001f < lo * aD) return false;       // t < lo
+        }
+    }
+    const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
+                     e2z_dy * cx - (d.z * cy) * e2x;
+    if (Dok) {
+        const bool negA = (__float_as_int(da) ^ sD) < 0; // da / D < 0
+        if (negA ? fabsf(da) >= tiny : fabsf(da) > aDm) return false; // a < 0, or a > 1 (then b < 0 or a + b > 1)
+    }
+    const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
+                     (cz * d.y) * e1x - dz_e1y * cx;
+    if (Dok) {
+        const bool negB = (__float_as_int(db) ^ sD) < 0;
+        if (negB && fabsf(db) >= tiny) return false; // b < 0
+        if (!negB && (__float_as_int(da) ^ sD) >= 0 && fabsf(da + db) > aDm) return false; // a + b > 1
+    }
+    if (D == 0.0f) { // Matrix33.h:132-134: solve() returns (0,0,0); t = -0.0f
+        a = 0.0f;
+        b = 0.0f;
+        t = -0.0f;
+    } else {
+        float q;
+        div3_rn(da, db, dt, D, a, b, q);
+        t = -q;
+    }
+    return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
+}
+
 #define RT_TRAV_EPS 1e-5f
 
 // Closest-hit (ANY = false) or any-hit (ANY = true) query over the KD tree.

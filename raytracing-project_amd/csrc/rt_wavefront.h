@@ -297,7 +297,8 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
 #endif
-            if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
+            if (tri_test_cell(q0, q1, q2, o, d, minT, tmin_e * 0.9999f, ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f), a,
+                              b, t)) {
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
                 bool      take = t != minT || best_orig < 0;
