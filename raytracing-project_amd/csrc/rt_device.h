@@ -256,6 +256,8 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
 // it and 6 % beyond the closest hit so far; 19 % cross inside the cell.  So t goes first (it went last
 // in tri_test, where only t < 0 and t > minT can be told) and the numerators of a and b are evaluated
 // for a fifth of the tests.  An any-hit walk passes hi = FLT_MAX: a hit beyond the cell ends it.
+// (D and the numerator of t are one expression in d and in c; evaluating the two as the halves of packed
+// FP32 operations brings the first stage from 45 to 38 instructions and changes nothing in the time.)
 __device__ __forceinline__ bool tri_test_cell(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d,
                                               float minT, float lo, float hi, float& a, float& b, float& t)
 {
