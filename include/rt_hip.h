@@ -232,6 +232,11 @@ int rt_normalize_depth_device(int device, int64_t n, float focus_depth, float *d
  * partial minima and maxima, 8 KB) in a fixed device array of the library
  * instead of the stream's memory pool.  Calls no hipMalloc / hipFree or any
  * other allocating routine.  n may not exceed RT_NOALLOC_MAX_DEPTH_VALUES.
+ * The array's address is looked up once per device (hipGetSymbolAddress, which
+ * may make the runtime load the library's code object): by rt_scene_create on
+ * that device, else by the first call here - a caller that has made no scene
+ * on the device makes one warm-up call before it enters the region in which it
+ * may not allocate.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU
  * (different streams or threads) race; calls on one stream are safe. */
 #define RT_NOALLOC_MAX_DEPTH_VALUES ((int64_t)1 << 28) /* a 16384 x 16384 frame */

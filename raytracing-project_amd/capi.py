@@ -280,6 +280,23 @@ class Scene:
                                     _ptr(depth), _ptr(tri), C.byref(st)))
         return rgb, depth, tri, st
 
+    def result_planes(self, corners, lights, params):
+        """rt_render_result_planes: the 8-bit planes of result.*, depth.bmp and blurred.bmp (copies;
+        the blurred plane is None for frames too small to blur)."""
+        cam = _f32(corners, (24,))
+        li = _f32(lights, (-1, 3))
+        W, H = params.width, params.height
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = RtStats()
+        check(lib().rt_render_result_planes(self.h, _ptr(cam), _ptr(li), len(li), C.byref(params), C.byref(a),
+                                            C.byref(b), C.byref(c), C.byref(st)))
+        rgb8 = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint8)), (H, W, 3)).copy()
+        depth8 = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), (H, W)).copy()
+        blur8 = None
+        if c.value:
+            blur8 = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint8)), (H - 12, W - 12, 3)).copy()
+        return rgb8, depth8, blur8, st
+
     def render_device(self, corners, lights, params, d_rgb, d_depth, d_tri, stream=0, stats=False):
         """Device-pointer form (integers from torch tensors' data_ptr())."""
         cam = _f32(corners, (24,))

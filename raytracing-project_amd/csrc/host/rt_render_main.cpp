@@ -10,6 +10,7 @@
 // before anything touches a GPU; they replace the reference's thread bands (main.cpp:329-339).
 // Rank 0 makes the RCCL unique id and hands it to the others through pipes, every rank renders
 // its tiles, rank 0 gathers them, post-processes and writes the files.
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -87,6 +88,12 @@ int main(int argc, char** argv)
                 return 1;
             }
             if (pid == 0) {
+                // keep only the ends this rank uses: a reader must see end-of-file when rank 0 dies before
+                // it has written the id, not wait on write ends its siblings still hold
+                for (int k = 1; k < n; ++k) {
+                    if (r != 0 && wr[k] >= 0) close(wr[k]);
+                    if (k != r && rd[k] >= 0) close(rd[k]);
+                }
                 unsigned char id[RT_RCCL_ID_BYTES];
                 void*         comm = nullptr;
                 if (n > 1) {
@@ -113,12 +120,38 @@ int main(int argc, char** argv)
             }
             kids.push_back(pid);
         }
-        int worst = 0;
-        for (pid_t k : kids) {
-            int st = 0;
-            waitpid(k, &st, 0);
+        for (int r = 1; r < n; ++r) close(rd[r]), close(wr[r]);
+        // A rank that fails leaves its peers waiting for it (in the communicator's set-up or in the
+        // gather): the first failure ends the others, so the program returns instead of hanging.
+        int    worst = 0;
+        bool   stopping = false;
+        size_t left = kids.size();
+        while (left > 0) {
+            int         st = 0;
+            const pid_t done = waitpid(-1, &st, 0);
+            if (done < 0) break;
+            size_t at = kids.size();
+            for (size_t i = 0; i < kids.size(); ++i)
+                if (kids[i] == done) at = i;
+            if (at == kids.size()) continue;
+            kids[at] = -1, --left;
             const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
             if (rc > worst) worst = rc;
+            if (rc != 0 && left > 0 && !stopping) {
+                stopping = true;
+                fprintf(stderr, "rank %zu failed (status %d): stopping the other %zu\n", at, rc, left);
+                for (pid_t k : kids)
+                    if (k > 0) kill(k, SIGTERM);
+                for (int tries = 0; tries < 50 && left > 0; ++tries) { // up to 5 s to go by themselves
+                    pid_t w;
+                    while (left > 0 && (w = waitpid(-1, &st, WNOHANG)) > 0)
+                        for (pid_t& k : kids)
+                            if (k == w) k = -1, --left;
+                    if (left > 0) usleep(100000);
+                }
+                for (pid_t k : kids)
+                    if (k > 0) kill(k, SIGKILL);
+            }
         }
         return worst;
     }

@@ -521,7 +521,7 @@ struct RtScene {
     // frame buffers of rt_render_result_planes: device planes + pinned host bytes, grown on demand
     void*       d_frame = nullptr;
     void*       h_frame = nullptr;
-    size_t      frame_px = 0;
+    size_t      frame_dev_bytes = 0, frame_host_bytes = 0; // what d_frame / h_frame hold
     hipStream_t frame_stream = nullptr;
     void*       d_share = nullptr; // tile payload of this rank (+ the gathered payloads on rank 0)
     size_t      share_bytes = 0;
@@ -559,6 +559,8 @@ static void timing_end(RtScene* s, int i, hipStream_t st)
 {
     if (i >= 0) (void)hipEventRecord(s->ev_pool[2 * i + 1], st);
 }
+
+static int scratch_for_device(int device, float** out); // the no-allocation entry point's array, below
 
 template <class T>
 static int upload(void** dptr, const std::vector<T>& v, size_t* total)
@@ -1128,6 +1130,14 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     if (texels.empty()) texels.assign(64, 0);
 
     HIP_TRY(hipSetDevice(device));
+    {
+        // The no-allocation entry point looks its array's address up once per device; doing it here means
+        // that a process which has made a scene on a device never does it (and whatever the runtime loads
+        // for it) inside that entry point.
+        float* unused = nullptr;
+        const int rc_s = scratch_for_device(device, &unused);
+        if (rc_s && rc_s != RT_ERR_UNSUPPORTED) return rc_s; // (a device number beyond that entry point's table)
+    }
     RtScene* s = new RtScene();
     s->device = device;
     s->tree_depth = max_depth;
@@ -1875,6 +1885,51 @@ static int normalize_depth_impl(int64_t n, float focus, float* d_depth, float* d
     return RT_OK;
 }
 
+// Scratch of the depth passes for the allocating entry points: one block of DEPTH_SCRATCH_FLOATS per
+// (device, stream), allocated at the first call on that stream and kept until the process ends.
+// Calls on one stream are ordered, so they may share a block; calls on different streams get
+// different blocks and may overlap.  (A hipMallocAsync / hipFreeAsync pair per call used to sit
+// inside every frame's post-process.)  Beyond DEPTH_SCRATCH_STREAMS streams per device a call takes
+// its block from the stream's memory pool as before.
+#define DEPTH_SCRATCH_STREAMS 64
+namespace {
+struct StreamScratch {
+    int         device;
+    hipStream_t stream;
+    float*      p;
+};
+std::vector<StreamScratch> g_stream_scratch;
+std::mutex                 g_stream_scratch_mutex;
+} // namespace
+
+static float* stream_scratch(int device, hipStream_t st) // `device` is current
+{
+    std::lock_guard<std::mutex> lock(g_stream_scratch_mutex);
+    size_t                      on_device = 0;
+    for (const StreamScratch& e : g_stream_scratch) {
+        if (e.device != device) continue;
+        if (e.stream == st) return e.p;
+        ++on_device;
+    }
+    if (on_device >= DEPTH_SCRATCH_STREAMS) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, DEPTH_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) return nullptr;
+    g_stream_scratch.push_back({device, st, p});
+    return p;
+}
+
+// Runs fn(scratch) with the stream's own block, or with one from the stream's memory pool.
+template <class F>
+static int with_depth_scratch(int device, hipStream_t st, F fn)
+{
+    if (float* p = stream_scratch(device, st)) return fn(p);
+    float* d_part = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_part, DEPTH_SCRATCH_FLOATS * sizeof(float), st));
+    const int rc = fn(d_part);
+    (void)hipFreeAsync(d_part, st);
+    return rc;
+}
+
 extern "C" int rt_normalize_depth_device(int device, int64_t n, float focus, float* d_depth,
                                          void* stream)
 {
@@ -1883,11 +1938,9 @@ extern "C" int rt_normalize_depth_device(int device, int64_t n, float focus, flo
     if (n < 0) return fail(RT_ERR_INVALID, "rt_normalize_depth: negative n");
     if (n == 0) return RT_OK;
     if (!d_depth) return fail(RT_ERR_INVALID, "rt_normalize_depth: null depth");
-    float* d_part = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&d_part, DEPTH_SCRATCH_FLOATS * sizeof(float), (hipStream_t)stream));
-    rc = normalize_depth_impl(n, focus, d_depth, d_part, (hipStream_t)stream);
-    (void)hipFreeAsync(d_part, (hipStream_t)stream);
-    return rc;
+    return with_depth_scratch(device, (hipStream_t)stream, [&](float* d_part) {
+        return normalize_depth_impl(n, focus, d_depth, d_part, (hipStream_t)stream);
+    });
 }
 
 // ---- the entry point that allocates nothing ----
@@ -1979,17 +2032,16 @@ extern "C" int rt_postprocess_device(int device, int32_t W, int32_t H, float foc
     if (blur && (W < 13 || H < 13)) return fail(RT_ERR_INVALID, "rt_postprocess: frame %dx%d must be at least 13x13 for the blur", W, H);
     if (blur && !d_rgb) return fail(RT_ERR_INVALID, "rt_postprocess: null rgb");
     hipStream_t st = (hipStream_t)stream_;
-    float*      d_part = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&d_part, DEPTH_SCRATCH_FLOATS * sizeof(float), st));
-    rc = normalize_depth_impl((int64_t)W * H, focus, d_depth, d_part, st, blur);
-    if (rc == RT_OK && blur) {
-        const unsigned n_blocks = (unsigned)(((W - 12 + DOF_TW - 1) / DOF_TW) * ((H - 12 + DOF_TH - 1) / DOF_TH));
-        hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, st, d_rgb, (const float*)d_depth, (int)W,
-                           (int)H, depth_power, d_blurred, (const float*)(d_part + 2 * RANGE_BLOCKS + 1), focus);
-        if (hipGetLastError() != hipSuccess) rc = fail(RT_ERR_HIP, "rt_postprocess: blur launch failed");
-    }
-    (void)hipFreeAsync(d_part, st);
-    return rc;
+    return with_depth_scratch(device, st, [&](float* d_part) {
+        int rc2 = normalize_depth_impl((int64_t)W * H, focus, d_depth, d_part, st, blur);
+        if (rc2 == RT_OK && blur) {
+            const unsigned n_blocks = (unsigned)(((W - 12 + DOF_TW - 1) / DOF_TW) * ((H - 12 + DOF_TH - 1) / DOF_TH));
+            hipLaunchKernelGGL(k_dof_blur, dim3(n_blocks), dim3(DOF_BLOCK), 0, st, d_rgb, (const float*)d_depth, (int)W,
+                               (int)H, depth_power, d_blurred, (const float*)(d_part + 2 * RANGE_BLOCKS + 1), focus);
+            if (hipGetLastError() != hipSuccess) rc2 = fail(RT_ERR_HIP, "rt_postprocess: blur launch failed");
+        }
+        return rc2;
+    });
 }
 
 extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, const float* rgb,
@@ -2041,13 +2093,19 @@ static int render_planes_impl(RtScene* s, void* comm, int rank, int n_ranks, con
                  o_rgb8 = o_blur + align256(12 * nbl + 16), o_depth8 = o_rgb8 + align256(3 * npx),
                  o_blur8 = o_depth8 + align256(npx), total = o_blur8 + align256(3 * nbl + 16);
     const size_t h_depth8 = align256(3 * npx), h_blur8 = h_depth8 + align256(npx), h_total = h_blur8 + align256(3 * nbl + 16);
-    if (s->frame_px != npx) {
+    // (sizes and offsets depend on the frame's shape, not only on its pixel count: 2 x 5000 has no
+    // blurred plane, 100 x 100 has one of 7744 pixels)
+    if (total > s->frame_dev_bytes) {
         if (s->d_frame) (void)hipFree(s->d_frame);
-        if (s->h_frame) (void)hipHostFree(s->h_frame);
-        s->d_frame = s->h_frame = nullptr, s->frame_px = 0;
+        s->d_frame = nullptr, s->frame_dev_bytes = 0;
         HIP_TRY(hipMalloc(&s->d_frame, total));
+        s->frame_dev_bytes = total;
+    }
+    if (h_total > s->frame_host_bytes) {
+        if (s->h_frame) (void)hipHostFree(s->h_frame);
+        s->h_frame = nullptr, s->frame_host_bytes = 0;
         HIP_TRY(hipHostMalloc(&s->h_frame, h_total, hipHostMallocDefault));
-        s->frame_px = npx;
+        s->frame_host_bytes = h_total;
     }
     if (!s->frame_stream) HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
     hipStream_t    st = s->frame_stream;

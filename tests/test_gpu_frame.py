@@ -222,6 +222,28 @@ def test_r_path_float_planes_and_row_updates(P, tmp_path):
     assert t["frame_call_ms"] > 0 and t["file_writes_ms"] > 0
 
 
+def test_result_planes_of_frames_with_equal_area_and_different_shape(P):
+    """rt_render_result_planes keeps its frame buffers between calls.  Their size depends on the frame's
+    shape, not only on its pixel count: 2 x 5000 has no blurred plane, 100 x 100 has one of 88 x 88 -
+    a square frame after a strip of the same area must get buffers of its own size, and every plane
+    must equal the one a fresh scene renders."""
+    hs, gs, m, lights = _host_gpu(P, "ball")
+    out = {}
+    for W, H in ((2, 5000), (100, 100), (5000, 2), (100, 100), (64, 30), (30, 64)):
+        corners = P.host.camera_corners(m, W, H)
+        out[(W, H)] = gs.result_planes(corners, lights, P.capi.default_params(W, H, 1))
+    for (W, H), (rgb8, depth8, blur8, st) in out.items():
+        fresh = hs.to_gpu(0)
+        f_rgb8, f_depth8, f_blur8, _ = fresh.result_planes(P.host.camera_corners(m, W, H), lights,
+                                                           P.capi.default_params(W, H, 1))
+        assert np.array_equal(rgb8, f_rgb8) and np.array_equal(depth8, f_depth8), (W, H)
+        assert (blur8 is None) == (f_blur8 is None) == (W <= 12 or H <= 12)
+        if blur8 is not None:
+            assert np.array_equal(blur8, f_blur8), (W, H)
+        fresh.close()
+    assert out[(100, 100)][0].std() > 0
+
+
 def test_focus_pick_then_r_path(P, oracle, tmp_path):
     """Key 'f' over a pixel, then 'r': a focus depth other than 0 makes the two depth
     normalisations differ (imageWriter.h:124-135, 352, 416); files against the oracle's."""

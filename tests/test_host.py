@@ -403,3 +403,19 @@ def test_png_decoder_reproduces_shipped_textures(P):
         assert np.array_equal(got, want), name
         n += 1
     assert n >= 7
+
+
+def test_rt_render_gpus_ends_when_a_rank_fails(P, tmp_path):
+    """`rt_render --gpus N` where a rank fails before the render (here: no GPU, so rank 0 cannot make the
+    unique id or no rank can make its communicator) must return non-zero promptly: the ranks close the
+    pipe ends they do not use, so a reader sees end-of-file, and the parent stops the survivors."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    exe = os.path.join(ROOT, "raytracing-project_amd", "csrc", "rt_render")
+    r = subprocess.run([exe, "--gpus", "3", os.path.join(SCENES, "ball.obj"),
+                        os.path.join(SCENES, "cameras", "ball.sav"), "64", "64", "1", str(tmp_path)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "rank" in r.stderr

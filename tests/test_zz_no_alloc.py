@@ -41,6 +41,14 @@ def test_noalloc_normalisation_equals_the_allocating_entry_point():
         P.capi.check(L.rt_normalize_depth_device_noalloc(0, d.size, 0.41, C.c_void_p(b.data_ptr()), C.c_void_p(st)))
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+    # after the calls above (the warm-up) the entry point takes no device memory: the free memory the
+    # driver reports is the same before and after a run of calls
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        P.capi.check(L.rt_normalize_depth_device_noalloc(0, d.size, 0.41, C.c_void_p(b.data_ptr()), C.c_void_p(st)))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
 
 
 def test_noalloc_rejects_what_it_cannot_serve():
