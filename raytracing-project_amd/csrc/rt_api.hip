@@ -118,7 +118,7 @@ k_check_hits(DScene S, long long n, const float* __restrict__ org, const float* 
         HitRec   h;
         nc = 1;
         const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
-        if (tri) tri[i] = got ? __float_as_int(S.tris[3 * h.slot + 2].w) : -1;
+        if (tri) tri[i] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w) : -1;
         if (a) a[i] = h.a;
         if (b) b[i] = h.b;
         if (t) t[i] = h.t;
@@ -185,7 +185,7 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
             HitRec h;
             nc = 1;
             const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
-            if (tri) tri[p] = got ? __float_as_int(S.tris[3 * h.slot + 2].w) : -1;
+            if (tri) tri[p] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w) : -1;
             hit_flag[slot] = got ? 1 : 0;
             if (!got) {
                 rgb[3 * p] = clamp01(P.bg[0]), rgb[3 * p + 1] = clamp01(P.bg[1]),
@@ -1055,7 +1055,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         const int axis = axis_of[k];
         dn.left = new_left[k];
         dn.split = dn.left >= 0 ? split_of[k] : 0.0f;
-        dn.tri_off = (int)(slots.size() / 3);
+        dn.tri_off = (int)(slots.size() / RT_SLOT_F4);
         if (lists[k].size() >= (1u << 28))
             return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: node triangle list too long");
         dn.cnt_axis = (int)lists[k].size() | (axis << 28);
@@ -1069,13 +1069,28 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             volatile float p1 = e1x * e2y, p4 = e1z * e2y;
             float          idx;
             memcpy(&idx, &t, 4);
+            // the plane head (tri_head_keep): (e1 x e2, (e1 x e2) . v2) / B in double, rounded once
+            const double a1[3] = {(double)e1x, (double)e1y, (double)e1z}, a2[3] = {(double)e2x, (double)e2y, (double)e2z};
+            double       nrm[3], B = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                const int j = (c + 1) % 3, l = (c + 2) % 3;
+                nrm[c] = a1[j] * a2[l] - a1[l] * a2[j];
+                B = std::max(B, std::fabs(a1[j] * a2[l]) + std::fabs(a1[l] * a2[j]));
+            }
+            float4 hd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (B > 9.1e-13 && B < 1.0e12) { // 2^-40 .. 2^40: no quantity of the reference's test leaves the normal range
+                const double kk = nrm[0] * (double)v2[0] + nrm[1] * (double)v2[1] + nrm[2] * (double)v2[2];
+                hd = make_float4((float)(nrm[0] / B), (float)(nrm[1] / B), (float)(nrm[2] / B), (float)(kk / B));
+                if (!std::isfinite(hd.w)) hd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            slots.push_back(hd);
             slots.push_back(make_float4(e1x, e1y, e1z, e2x));
             slots.push_back(make_float4(e2y, e2z, v2[0], v2[1]));
             slots.push_back(make_float4(v2[2], p1, p4, idx));
         }
         nodes[k] = dn;
     }
-    if (slots.size() / 3 >= (1u << 30))
+    if (slots.size() / RT_SLOT_F4 >= (1u << 28))
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many triangle references");
     std::vector<uint2> knodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); ++k) {
@@ -1176,9 +1191,16 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.tri_rank = (const int32_t*)s->d_rank;
     s->d.knodes = (const uint2*)s->d_knodes;
     s->d.n_nodes = (int)nodes.size();
-    s->d.n_slots = (int)(slots.size() / 3);
+    s->d.n_slots = (int)(slots.size() / RT_SLOT_F4);
     s->d.n_triangles = nt;
     s->d.stack_entries = max_depth + 1;
+    {
+        float v = 0.0f;
+        for (int i = 0; i < nv; ++i)
+            v = std::max(v, std::fabs(desc->vertex_pos[3 * i]) + std::fabs(desc->vertex_pos[3 * i + 1]) +
+                                std::fabs(desc->vertex_pos[3 * i + 2]));
+        s->d.vert_l1 = v * 1.000001f;
+    }
     s->pushdown = pushdown;
     {
         uint64_t h = 1469598103934665603ull;
@@ -1186,7 +1208,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             for (int b = 0; b < 4; ++b) h = (h ^ ((v >> (8 * b)) & 0xffu)) * 1099511628211ull;
         };
         for (const uint2& k : knodes) mix(k.x), mix(k.y);
-        for (size_t i = 0; i < slots.size() / 3; ++i) mix((uint32_t)__builtin_bit_cast(int32_t, slots[3 * i + 2].w));
+        for (size_t i = 0; i < slots.size() / RT_SLOT_F4; ++i) mix((uint32_t)__builtin_bit_cast(int32_t, slots[RT_SLOT_F4 * i + 3].w));
         s->tree_hash = h;
     }
     s->tree_ms = (float)tree_ms, s->tree_on_gpu = tree_on_gpu ? 1 : 0;
@@ -1324,13 +1346,15 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
     st->child_rays = c.child_rays;
 #ifdef WF_DIAG
     {
-        unsigned long long d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long d[16] = {0}, z[16] = {0};
         (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_diag), sizeof d);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z);
         fprintf(stderr, "diag: node loop lanes %.4f (%llu of %llu), triangle loop lanes %.4f (%llu of %llu)\n",
                 (double)c.node_visits / (double)(d[0] ? d[0] : 1), (unsigned long long)c.node_visits, d[0],
                 (double)c.tri_tests / (double)(d[1] ? d[1] : 1), (unsigned long long)c.tri_tests, d[1]);
         fprintf(stderr, "diag: leaf visits: %llu empty, %llu with triangles\n", d[2], d[3]);
+        fprintf(stderr, "diag: triangle loop: %llu wave trips, %llu with a lane past the plane head (%.3f), %llu such lanes (%.3f of the tests)\n",
+                d[1] / 64, d[8], (double)d[8] / (double)(d[1] ? d[1] / 64 : 1), d[9], (double)d[9] / (double)(c.tri_tests ? c.tri_tests : 1));
         fprintf(stderr, "diag: shadow rays %llu, occluded %llu, their tests %llu and node steps %llu\n", d[4], d[5], d[6], d[7]);
     }
 #endif

@@ -35,7 +35,8 @@ struct DNode {
 // Triangle slots: every node's list in node order; a triangle may be listed by
 // several leaves.  Ties in t go to the triangle the reference's walk would have
 // tested last on its root-to-leaf path (raytracing.cpp:311-338), recorded per
-// triangle in DScene::tri_rank.  Three float4 per slot:
+// triangle in DScene::tri_rank.  Four float4 (64 bytes, half a cache line) per slot:
+//   hd = n.x n.y n.z k            the triangle's plane, scaled (tri_head_keep)
 //   q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
 //   q1 = e2.y e2.z v2.x v2.y
 //   q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
@@ -43,6 +44,7 @@ struct DNode {
 //   inner: x = bits(split plane), y = axis << 30 | index of the left child
 //   leaf : x = first triangle slot, y = 3 << 30 | triangle count
 // (only built when inner nodes carry no triangles of their own).
+#define RT_SLOT_F4 4 // float4 per triangle slot
 struct DScene {
     const DNode*   nodes;
     const uint2*   knodes;
@@ -59,7 +61,8 @@ struct DScene {
     // ones in stk_spill / stk_spill_t (per block: [entry - stk_cap][thread])
     unsigned short* stk_spill;
     float*          stk_spill_t;
-    int32_t         stk_cap, pad;
+    int32_t         stk_cap;
+    float           vert_l1; // largest |x| + |y| + |z| over the vertices (tri_head_keep's bound on n . v2)
 };
 
 struct DParams {
@@ -307,6 +310,45 @@ __device__ __forceinline__ bool tri_test_cell(const float4 q0, const float4 q1, 
     return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
 }
 
+// The plane head of a slot, and what it decides.  With n = e1 x e2, the determinant of the reference's test is
+// D = n . dir and the numerator of t is N = n . (o - v2), t = -(N / D): where the ray crosses the triangle's
+// plane.  A walk that knows the stretch [lo, hi] of the ray inside its cell (tri_test_cell) drops four tests in
+// five on D and N alone - and evaluates both in the reference's operation order to do so, 45 instructions.
+// That decision only has to be safe, not bit-exact: the head holds (n, n . v2) divided by
+// B = max_i (|e1_j e2_k| + |e1_k e2_j|), so that every component of the scaled normal, and of the sum of
+// absolute products behind it, is at most 1.  Then
+//   |D_ref / B - Dh| <= 11 * 2^-24 * (|dx| + |dy| + |dz|)            (7 roundings of the reference's sum of
+//   |N_ref / B - Nh| <= 13 * 2^-24 * (|ox| + |oy| + |oz| + V)         six triple products, the rest ours)
+// with V >= |v2x| + |v2y| + |v2z|: two numbers per ray (tri_head_bounds: eD = 2^-20 * ..., eN = 2^-19 * ...,
+// neither below 2^-60, so that what is called certain stays clear of underflow in the reference's quotient
+// with B in [2^-40, 2^40]), no per-test error arithmetic.  The test is dropped only if t < 0, t > hi or t < lo holds for every (D, N) within those bounds
+// and the sign of D is certain; anything else goes on to tri_test_cell unchanged, so hits and their a, b, t
+// stay the reference's bits.  A degenerate triangle (B = 0 or not finite) has a zero head: never dropped.
+__device__ __forceinline__ void tri_head_bounds(f3 o, f3 d, float vert_l1, float& eD, float& eN)
+{
+    const float sd = fabsf(d.x) + fabsf(d.y) + fabsf(d.z), so = fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + vert_l1;
+    const float huge = 1.1529215e18f, floor_ = 8.6736174e-19f, inf = __builtin_inff(); // 2^60, 2^-60
+    eD = sd < huge ? fmaxf(sd * 9.5367432e-7f, floor_) : inf; // (not less-than also catches NaN: no test is dropped)
+    eN = so < huge ? fmaxf(so * 1.9073486e-6f, floor_) : inf;
+}
+
+__device__ __forceinline__ bool tri_head_keep(const float4 hd, f3 o, f3 d, float eD, float eN, float lo_s,
+                                              float hi_s)
+{
+    // lo_s = lo / 1.000001, hi_s = hi * 1.000001 (the rounding of the reference's quotient)
+    const float Dh = __builtin_fmaf(hd.x, d.x, __builtin_fmaf(hd.y, d.y, hd.z * d.z));
+    const float Nh = __builtin_fmaf(hd.x, o.x, __builtin_fmaf(hd.y, o.y, __builtin_fmaf(hd.z, o.z, -hd.w)));
+    const float lowD = fabsf(Dh) - eD, upD = fabsf(Dh) + eD; // |D| / B lies in [lowD, upD]
+    // nq = N sign(D) = -t |D|
+    const float nq = __uint_as_float(__float_as_uint(Nh) ^ (__float_as_uint(Dh) & 0x80000000u));
+    // (no short circuits: one straight run of instructions, no branch around half of it)
+    const int sure = lowD > 0.0f;
+    const int behind = nq > eN;                 // t < 0
+    const int beyond = nq + eN < -(hi_s * upD); // t > hi
+    const int before = eN - nq < lo_s * lowD;   // t < lo
+    return !(sure & (behind | beyond | before));
+}
+
 #define RT_TRAV_EPS 1e-5f
 
 // Closest-hit (ANY = false) or any-hit (ANY = true) query over the KD tree.
@@ -335,14 +377,14 @@ __device__ __forceinline__ bool kd_trace(const DScene& S, f3 o, f3 dst, uint2* s
         const int cnt = nd.cnt_axis & 0x0fffffff;
         for (int i = 0; i < cnt; ++i) {
             const int    slot = nd.tri_off + i;
-            const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
+            const float4 q0 = S.tris[RT_SLOT_F4 * slot + 1], q1 = S.tris[RT_SLOT_F4 * slot + 2], q2 = S.tris[RT_SLOT_F4 * slot + 3];
             float        a, b, t;
             ++n_tests;
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
                 bool take = t != minT || h.slot < 0;
                 if (!take) { // equal t: keep the one the reference's test order ends with
-                    const int cur = __float_as_int(S.tris[3 * h.slot + 2].w);
+                    const int cur = __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w);
                     take = S.tri_rank[__float_as_int(q2.w)] > S.tri_rank[cur];
                 }
                 if (take) h.slot = slot, h.a = a, h.b = b, minT = t;
@@ -445,7 +487,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
         ++n_closest;
         const bool got = kd_trace<false>(S, r.o, r.d, stk, stride, hit, n_tests, n_nodes);
         int orig = -1;
-        if (got) orig = __float_as_int(S.tris[3 * hit.slot + 2].w);
+        if (got) orig = __float_as_int(S.tris[RT_SLOT_F4 * hit.slot + 3].w);
         if (first) {
             minT_out = hit.t;
             tri_out = orig;

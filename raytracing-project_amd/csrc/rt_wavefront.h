@@ -234,7 +234,9 @@ __device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
 // Diagnostic builds only (-DWF_DIAG): lane slots (wave trips x 64) of the node loop and of the triangle
 // loop of the counted launch; rt_api.hip prints them against the lanes that did work (final.obj 4K MSAA4:
 // 94 % in the node loop, 69 % in the triangle loop).
-__device__ unsigned long long g_diag[8]; // [4..7]: shadow rays traced / occluded, their triangle tests / node steps
+__device__ unsigned long long g_diag[16]; // [4..7]: shadow rays traced / occluded, their triangle tests / node steps;
+                                         // [8] wave trips of the triangle loop in which a lane passes the plane head, [9] such lanes,
+                                         // [10] leaf visits by waves (trips of the outer loop), [11] lanes entering a leaf with triangles
 #endif
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
@@ -252,6 +254,8 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 iy = d.y != 0.0f ? __builtin_amdgcn_rcpf(d.y) : big,
                 iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
     const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    float       eD, eN; // the plane heads' error bounds for this ray
+    tri_head_bounds(o, d, S.vert_l1, eD, eN);
     for (;;) {
         uint2 nd = S.knodes[node];
         if (COUNT) ++n_nodes;
@@ -289,21 +293,41 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #ifdef WF_DIAG
         if (COUNT) atomicAdd(&g_diag[cnt == 0 ? 2 : 3], 1ull);
 #endif
+        const float lo = tmin_e * 0.9999f, hi = ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f);
+        const float lo_s = lo * 0.999999f;
+        float       hi_s = hi * 1.000001f;
         for (int i = 0; i < cnt; ++i) {
-            const int    slot = first + i;
-            const float4 q0 = S.tris[3 * slot], q1 = S.tris[3 * slot + 1], q2 = S.tris[3 * slot + 2];
-            float        a, b, t;
+            const int     slot = first + i;
+            const float4* rec = S.tris + (size_t)RT_SLOT_F4 * slot;
+            float4        hd = rec[0];
+#ifdef WF_HEAD_SPECULATIVE // the rest of the slot asked for with the head and waited for only by survivors: 8.08 vs 7.67 ms
+            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
+#endif
             if (COUNT) ++n_tests;
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
 #endif
-            if (tri_test_cell(q0, q1, q2, o, d, minT, tmin_e * 0.9999f, ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f), a,
-                              b, t)) {
+            // (the head as one 16-byte load, complete here: the compiler would otherwise fetch its last word
+            // later, behind a wait for the whole slot)
+            asm volatile("" ::"v"(hd.x), "v"(hd.y), "v"(hd.z), "v"(hd.w));
+#ifdef WF_DIAG
+            if (COUNT) {
+                const bool k_ = tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s);
+                const unsigned long long a_ = __ballot(1), m_ = __ballot(k_);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[8], 1ull), atomicAdd(&g_diag[9], (unsigned long long)__popcll(m_));
+            }
+#endif
+            if (!tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s)) continue;
+#ifndef WF_HEAD_SPECULATIVE
+            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
+#endif
+            float a, b, t;
+            if (tri_test_cell(q0, q1, q2, o, d, minT, lo, ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f), a, b, t)) {
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
                 bool      take = t != minT || best_orig < 0;
                 if (!take) take = S.tri_rank[orig] > S.tri_rank[best_orig];
-                if (take) h.a = a, h.b = b, minT = t, best_orig = orig;
+                if (take) h.a = a, h.b = b, minT = t, best_orig = orig, hi_s = fminf(hi_s, t * 1.000001f);
             }
         }
         // A pending subtree starts where the cell above it on the stack ends, give or take the
