@@ -100,6 +100,9 @@ def lib():
     L.or_trace_rays.argtypes = [P, C.c_int, fp, fp, fp, fp, ip, C.c_int, cp]
     L.or_check_hits.argtypes = [P, C.c_int, fp, fp, ip, fp, fp, fp, fp, C.c_int, cp]
     L.or_brute_hits.argtypes = [P, C.c_int, fp, fp, ip, fp]
+    L.or_guard_rays.argtypes = [fp, C.c_int]
+    L.or_guard_rays.restype = C.c_int
+    L.or_guard_reset.restype = None
     L.or_camera_corners.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
                                     C.c_int, C.c_int, fp]
     L.or_pixel_ray.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, fp, fp]
@@ -284,6 +287,15 @@ class Scene:
                                C.byref(counters) if counters is not None else None,
                                C.byref(centre) if centre is not None else None)
         return rgb, depth, tri
+
+
+def guard_rays(reset=True):
+    """Rays whose leaf walk the step guard stopped since the last reset: (n, 6) origin + destination."""
+    out = np.zeros((64, 6), np.float32)
+    n = lib().or_guard_rays(out, 64)
+    if reset:
+        lib().or_guard_reset()
+    return out[:min(n, 64)].copy()
 
 
 def camera_corners(modelview, W, H):

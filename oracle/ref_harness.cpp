@@ -10,21 +10,36 @@
  * (mesh.cpp:32), buildKDtree/splitSpaces/calcBestSplit (KDtree.cpp:15-230),
  * findChildNode/findNextNode/contains (KDtree.cpp:235-605), checkHit and
  * performRayTracing (raytracing.cpp:61-386) with Vec3D.h/Matrix33.h.
- * What does not: Mesh::loadMesh (needs Corona), so the mesh is handed over
- * through the public members of Mesh/Material; main.cpp (GLUT) and
- * imageWriter.h (std::powf) are not compiled.
+ * Mesh::loadMtl (mesh.cpp:354-480) runs unmodified too (mode --mtl): it never
+ * touches the image library.  Material::getTexture / getTexture2
+ * (mesh.cpp:485-553) run unmodified on pixels this harness hands over: the
+ * members Corona would have filled (texturePixels, textureWidth, textureHeight,
+ * containsTexture, mesh.h:164-168) are private, so this one translation unit
+ * sees the reference's headers with `private` spelled `public` (the standard
+ * headers are included before that; mesh.cpp itself is compiled as it lies).
+ * What does not run: Mesh::loadMesh (needs Corona), so the mesh is handed over
+ * through the members of Mesh/Material; main.cpp (GLUT) is not compiled.
  *
  * Built as _ref/libref.so; _ref/refprobe (ref_driver.c) loads it with lazy
  * binding, because Mesh::loadMesh's call into Corona stays an undefined symbol.
  *
  * usage: refprobe <scene.bin> <rays.bin> <out.bin>
+ *        refprobe --mtl <file.mtl> <out.bin>
  */
+#include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "config.h"
+#define private public
 #include "raytracing.h"
+#undef private
 #include "settings.h"
 
 // KDtree.cpp is compiled as part of this unit so that its inline walk helpers
@@ -66,8 +81,47 @@ static void dumpTree(FILE *out, const AccelTreeNode &n)
     }
 }
 
+static void putStr(FILE *out, const std::string &s)
+{
+    int n = (int)s.size();
+    fwrite(&n, 4, 1, out);
+    if (n) fwrite(s.data(), 1, n, out);
+}
+
+// --mtl: Mesh::loadMtl on one file; per material, in file order: name, Kd, Ks, Ns, Ni, illum, Tr,
+// the has_* flags of its own block, the texture name.  Fields no line has set yet hold whatever
+// the reference's uninitialised `Material mat` (mesh.cpp:369) holds: the reader of this dump
+// compares only fields that some line at or above the material's block has set.
+static int mtlMain(const char *path, const char *outPath)
+{
+    FILE *out = fopen(outPath, "wb");
+    if (!out) return 1;
+    Mesh                                mesh;
+    std::map<std::string, unsigned int> index;
+    const bool                          ok = mesh.loadMtl(path, index);
+    int                                 n = ok ? (int)mesh.materials.size() : -1;
+    fwrite(&n, 4, 1, out);
+    for (int i = 0; i < n; ++i) {
+        Material &m = mesh.materials[i];
+        putStr(out, m.name());
+        float v[9] = {m.Kd()[0], m.Kd()[1], m.Kd()[2], m.Ks()[0], m.Ks()[1], m.Ks()[2], m.Ns(), m.Ni(), m.Tr()};
+        fwrite(v, 4, 9, out);
+        int w[2] = {m.illum(), (m.has_Kd() ? 1 : 0) | (m.has_Ka() ? 2 : 0) | (m.has_Ks() ? 4 : 0) | (m.has_Ns() ? 8 : 0) |
+                                   (m.has_Ni() ? 16 : 0) | (m.has_illum() ? 32 : 0) | (m.has_Tr() ? 64 : 0)};
+        fwrite(w, 4, 2, out);
+        putStr(out, m.textureName());
+        int idx = -1;
+        for (auto &kv : index)
+            if ((int)kv.second == i) idx = 1;
+        fwrite(&idx, 4, 1, out);
+    }
+    fclose(out);
+    return 0;
+}
+
 extern "C" int ref_main(int argc, char **argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "--mtl")) return mtlMain(argv[2], argv[3]);
     if (argc < 4) return 1;
     FILE *fs = fopen(argv[1], "rb");
     FILE *fr = fopen(argv[2], "rb");
@@ -92,6 +146,20 @@ extern "C" int ref_main(int argc, char **argv)
     rd(fs, &nl, 4);
     std::vector<float> lights(3 * nl);
     rd(fs, lights.data(), 12 * nl);
+    // optional: textures as the image library would have delivered them (RGBA8, top row first), each
+    // followed by the two zero rows that make the over-read of mesh.cpp:499 defined; the material rows
+    // name their texture in field 10 (-1: none)
+    int ntex = 0;
+    if (fread(&ntex, 4, 1, fs) != 1) ntex = 0;
+    static std::vector<std::vector<unsigned char>> texPixels;
+    std::vector<int>                               texW(ntex), texH(ntex);
+    texPixels.resize(ntex);
+    for (int i = 0; i < ntex; ++i) {
+        rd(fs, &texW[i], 4);
+        rd(fs, &texH[i], 4);
+        texPixels[i].resize((size_t)texW[i] * (texH[i] + 2) * 4);
+        rd(fs, texPixels[i].data(), texPixels[i].size());
+    }
     fclose(fs);
 
     for (int i = 0; i < nv; ++i)
@@ -113,6 +181,13 @@ extern "C" int ref_main(int argc, char **argv)
         m.set_Ns(r[6]);
         m.set_illum((int)r[8]);
         if (r[9] != 0.0f) m.set_Ni(r[7]);
+        const int tex = (int)r[10];
+        if (ntex > 0 && tex >= 0 && tex < ntex) { // what Material::loadTexture (mesh.h:117-135) leaves behind
+            m.containsTexture = true;
+            m.texturePixels = texPixels[tex].data();
+            m.textureWidth = texW[tex];
+            m.textureHeight = texH[tex];
+        }
         MyMesh.materials.push_back(m);
     }
     MyLightPositions.clear();

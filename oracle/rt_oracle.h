@@ -8,15 +8,20 @@
  * (paths are relative to the reference checkout).
  *
  * Parity status: the KD build, the leaf walk, the ray/triangle test, the
- * shading recursion (raytracing.cpp, KDtree.cpp, mesh.cpp's normals) and the
- * image code (imageWriter.h: RGBValue clamp, depth normalisation, the 13x13
- * depth-of-field kernel, the blur, the PPM/BMP writers and the per-row update)
- * are pinned against the reference's own sources compiled in the build
- * container (oracle/_ref, see oracle/Makefile; vectors in tests/golden/).
- * The OBJ/MTL loader, the texture lookup and the frame driver (corner rays,
- * per-pixel ray, MSAA) are restated from reading the source only - PARITY
- * UNPINNED for those, because the reference files that hold them need
- * libraries this image lacks (Corona, GLU/GLUT).
+ * shading recursion (raytracing.cpp, KDtree.cpp, mesh.cpp's normals), the
+ * material loader (Mesh::loadMtl, mesh.cpp:354-480, with the fields that leak
+ * from one newmtl block into the next), the texture lookup
+ * (Material::getTexture / getTexture2, mesh.cpp:485-553, on the .rtex pixels
+ * + two zero rows) and the image code (imageWriter.h: RGBValue clamp, depth
+ * normalisation, the 13x13 depth-of-field kernel, the blur, the PPM/BMP
+ * writers and the per-row update) are pinned against the reference's own
+ * sources compiled in the build container (oracle/_ref, see oracle/Makefile;
+ * vectors in tests/golden/).  The OBJ geometry parser (Mesh::loadMesh,
+ * mesh.cpp:96-350: it calls into the Corona image library) and the frame
+ * driver (corner rays, per-pixel ray, MSAA composition; main.cpp needs
+ * GLU/GLUT) are restated from reading the source only - PARITY UNPINNED for
+ * those two, because the reference files that hold them need libraries this
+ * image lacks.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
@@ -123,6 +128,10 @@ void or_trace_rays(const or_scene *s, int n, const float *origins, const float *
 void or_check_hits(const or_scene *s, int n, const float *origins, const float *dests,
                    int32_t *tri, float *a, float *b, float *t, float *hitPoint, int threads,
                    or_counters *c);
+/* rays whose leaf walk was stopped by the step guard since the last reset (origin, destination; at most
+ * 64 are kept); returns how many there were */
+int  or_guard_rays(float *out6, int max);
+void or_guard_reset(void);
 /* brute force over all triangles with the same triangle test (diagnostic) */
 void or_brute_hits(const or_scene *s, int n, const float *origins, const float *dests,
                    int32_t *tri, float *t);

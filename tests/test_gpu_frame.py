@@ -338,6 +338,26 @@ def test_full_size_frames_against_the_reference(P, oracle, key):
         assert (np.abs(depth[y, x][both] - g["depth"][both]) <= 1e-6 * g["depth"][both]).mean() >= 0.9995
 
 
+@pytest.mark.parametrize("key", [k for k in sorted(FC) if FC[k]["scene"] in ("lego", "final")])
+def test_full_size_textured_frames_against_the_reference(P, oracle, key):
+    """The two textured BASELINE configs at full size, WITH their textures, against the REAL reference:
+    20000 seeded pixels whose camera rays went through the reference's performRayTracing with
+    Material::getTexture (mesh.cpp:485-553) reading the .rtex pixels + two zero rows
+    (tools/make_tex_golden.py, fixture sparse_reftex_*.npz).  Scene through the product's own loader."""
+    cfg = FC[key]
+    g = np.load(os.path.join(GOLDEN, f"sparse_reftex_{key}.npz"))
+    hs, gs, m, lights = _host_gpu(P, cfg["scene"])
+    W, H = cfg["width"], cfg["height"]
+    rgb, depth, tri, st = gs.render(g["corners"], g["lights"], P.capi.default_params(W, H, cfg["msaa"]))
+    x, y = g["x"], g["y"]
+    assert (tri[y, x] == g["tri"]).mean() >= 0.9999
+    d = np.abs(oracle.to_bytes(rgb[y, x]).astype(int) - g["rgb8"].astype(int)).max(axis=1)
+    assert (d <= 1).mean() >= 0.999, f"{(d > 1).sum()} of {d.size} sampled pixels off by > 1 LSB"
+    assert (d == 0).mean() >= 0.98
+    u = np.load(os.path.join(GOLDEN, f"sparse_ref_{key}.npz"))
+    assert (u["rgb8"] != g["rgb8"]).any(axis=1).mean() > 0.01      # textured and untextured frames do differ
+
+
 def test_bad_arguments_are_rejected(P):
     hs, gs, m, lights = _host_gpu(P, "ball")
     L = P.capi.lib()

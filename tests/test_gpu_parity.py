@@ -78,6 +78,23 @@ def test_trace_rays_untextured_match_reference(oracle, name):
     assert (diff <= 1).mean() >= 0.999
 
 
+@pytest.mark.parametrize("name", ["lego", "final"])
+def test_trace_rays_textured_match_reference(oracle, name):
+    """The same rays with the scenes' textures: colours the reference's own Material::getTexture
+    (mesh.cpp:485-553) produced on the .rtex pixels + two zero rows (tools/make_tex_golden.py) - through
+    the product's loader, so the material table with its inherited texture names is part of what is compared."""
+    P = pkg()
+    g, t = load_golden(name), load_golden("reftex_" + name)
+    gs = P.host.HostScene(os.path.join(SCENES, name + ".obj")).to_gpu(0)
+    rgb, mt, tri, _ = gs.trace_rays(g["origins"], g["dests"], g["lights"])
+    same = tri == g["ref_tri"]
+    assert same.mean() >= 1 - 1e-4 and np.array_equal(mt[same], g["ref_minT"][same])
+    q, rq = oracle.to_bytes(np.clip(rgb, 0, 1)), oracle.to_bytes(np.clip(t["ref_rgb_tex"], 0, 1))
+    diff = np.abs(q.astype(int) - rq.astype(int)).max(axis=1)
+    assert (diff <= 1).mean() >= 0.999 and (diff == 0).mean() >= 0.98
+    assert (np.abs(rgb - t["ref_rgb_tex"]).max(axis=1) < 1e-4).mean() >= 0.999
+
+
 @pytest.mark.parametrize("name,msaa,W,H", [("ball", 1, 200, 200), ("redballs", 1, 240, 135),
                                           ("refractionballs", 1, 240, 135),
                                           ("lego", 4, 240, 135), ("final", 4, 240, 135),

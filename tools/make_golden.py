@@ -38,7 +38,7 @@ SCENES = {
 N_RANDOM = 3000
 
 
-def scene_blob(s, lights):
+def scene_blob(s, lights, textured=False):
     vpos, _ = s.vertices()
     tv, tt, tm = s.triangles()
     tc = s.texcoords()
@@ -49,6 +49,12 @@ def scene_blob(s, lights):
     b += struct.pack("<i", len(tc)) + tc.astype("<f4").tobytes()
     b += struct.pack("<i", len(mats)) + mats.astype("<f4").tobytes()
     b += struct.pack("<i", len(lights)) + lights.astype("<f4").tobytes()
+    if textured:  # pixels as the image library would deliver them + the two zero rows; material rows name them
+        tex = s.textures()
+        b += struct.pack("<i", len(tex))
+        for px, w, h in tex:
+            assert px.size == (h + 2) * w * 4 and not px[h * w * 4:].any()
+            b += struct.pack("<2i", w, h) + px.tobytes()
     return b
 
 
@@ -101,11 +107,11 @@ def parse_tree(buf, pos):
                      tris=np.array(tris, np.int32))
 
 
-def run_ref(s, lights, o, d):
+def run_ref(s, lights, o, d, textured=False):
     probe = os.path.join(ROOT, "oracle", "_ref", "refprobe")
     with tempfile.TemporaryDirectory() as td:
         fs, fr, fo = (os.path.join(td, n) for n in ("scene.bin", "rays.bin", "out.bin"))
-        open(fs, "wb").write(scene_blob(s, lights))
+        open(fs, "wb").write(scene_blob(s, lights, textured))
         open(fr, "wb").write(struct.pack("<i", len(o)) + o.astype("<f4").tobytes()
                              + d.astype("<f4").tobytes())
         subprocess.run([probe, fs, fr, fo], check=True, stdout=subprocess.DEVNULL)
