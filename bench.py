@@ -29,8 +29,9 @@ against the committed fixture of the CPU oracle, blurred pixels against the
 oracle's kernel; a mismatch fails the run ("checked" in the line).  On one GPU
 the line also carries a record per other BASELINE config ("configs"), the wall
 time of the drop-in 'r' path ("r_path_ms"), an eighth of the frame alone and with two frames in flight
-("frame_parts_in_flight": what a rank of eight GPUs would render; "whole_frames_in_flight": the
-throughput of this GPU with two whole frames in flight) and the CPU baseline.
+("frame_parts_in_flight": what a rank of eight GPUs would render) and the CPU baseline.  For every N the
+K steps are timed twice: with one frame in flight (the line's value and ms_per_step: the time of a
+frame) and with two ("two_frames_in_flight": the throughput of consecutive frames).
 """
 import argparse
 import importlib
@@ -43,7 +44,8 @@ import time
 # different hardware queues.  The runtime's default of four queues per process, shared with every other
 # stream the process makes, left two frames in flight running one after the other (an eighth of the
 # 4K frame: 1.90 ms per part); with eight queues they overlap (1.24 ms).  Read by the HIP runtime when
-# it starts, so it is set before anything touches the GPU.
+# it starts, so it is set before anything touches the GPU - and only if the environment does not set it
+# already (a pool that fixes it at four keeps four; the partner probe below copes with that).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -106,6 +108,9 @@ def cpu_baseline(corners, lights):
                      "rows": bands * rows, "runs": 5, "mean_run_s": round(dt, 3)}
     best = max(res.values(), key=lambda r: r["mrays_s"])
     return {"value": best["mrays_s"], "unit": "Mrays/s", "cores": best["threads"], "kind": "port",
+            "value_counts": "the queries the REFERENCE's walk makes (251 M per frame, discarded centre-ray subtrees and "
+                            "moot shadow queries included); the GPU line's value counts the 128 M the GPU traces - "
+                            "compare ms per frame (ms_per_frame_extrapolated against ms_per_step), not Mrays/s",
             "host_cpu_count": os.cpu_count(), "cpu_share": share, "extrapolated": True,
             "protocol": "mean of 5 runs after 1 warm-up (main.cpp:261-267), render loop only, no file writes",
             "sample": f"{best['rows']} of {H} rows ({bands} bands) of {SCENE}.obj {W}x{H} MSAA{MSAA}, no DoF, "
@@ -213,24 +218,32 @@ def config_record(pkg, name, w, h, msaa, fc, dev_index, frames=5):
 
 
 def check_sparse(key, rgb, depth, tri=None):
-    """20000 seeded pixels of the full-size frame against the committed fixture of the CPU
-    oracle (tests/golden/sparse_<config>.npz): 8-bit RGB within 1 LSB on >= 99.9 %, misses agree
-    and depth within 1e-5 on >= 99.95 %, pixel-centre triangle equal on >= 99.99 %."""
+    """20000 seeded pixels of the full-size frame against two committed fixtures: the CPU oracle's frame
+    (tests/golden/sparse_<config>.npz) and the pixels the REAL reference's own performRayTracing composes to
+    (sparse_reftex_<config>.npz for the two textured scenes, sparse_ref_<config>.npz for the others, which
+    have no texture to load).  8-bit RGB within 1 LSB on >= 99.9 %, misses agree and depth within 1e-5 on
+    >= 99.95 %, pixel-centre triangle equal on >= 99.99 %."""
     from oracle import oracle as O
-    path = os.path.join(ROOT, "tests", "golden", f"sparse_{key}.npz")
-    if not os.path.exists(path):
+    gold = os.path.join(ROOT, "tests", "golden")
+    ref = os.path.join(gold, f"sparse_reftex_{key}.npz")
+    if not os.path.exists(ref):
+        ref = os.path.join(gold, f"sparse_ref_{key}.npz")
+    paths = [q for q in (os.path.join(gold, f"sparse_{key}.npz"), ref) if os.path.exists(q)]
+    if not paths:
         return None
-    g = np.load(path)
-    x, y = g["x"], g["y"]
-    d = np.abs(O.to_bytes(rgb[y, x]).astype(int) - g["rgb8"].astype(int)).max(axis=1)
-    ok = (d <= 1).mean() >= 0.999
-    miss = g["depth"] == np.float32(3.402823466e+38)
-    got = depth[y, x]
-    ok = ok and ((got == np.float32(3.402823466e+38)) == miss).mean() >= 0.9999
-    both = ~miss & (got != np.float32(3.402823466e+38))
-    ok = ok and (np.abs(got[both] - g["depth"][both]) <= 1e-5 * g["depth"][both]).mean() >= 0.9995
-    if tri is not None:
-        ok = ok and (tri[y, x] == g["tri"]).mean() >= 0.9999
+    ok = True
+    for path in paths:
+        g = np.load(path)
+        x, y = g["x"], g["y"]
+        d = np.abs(O.to_bytes(rgb[y, x]).astype(int) - g["rgb8"].astype(int)).max(axis=1)
+        ok = ok and (d <= 1).mean() >= 0.999
+        miss = g["depth"] == np.float32(3.402823466e+38)
+        got = depth[y, x]
+        ok = ok and ((got == np.float32(3.402823466e+38)) == miss).mean() >= 0.9999
+        both = ~miss & (got != np.float32(3.402823466e+38))
+        ok = ok and (np.abs(got[both] - g["depth"][both]) <= 1e-5 * g["depth"][both]).mean() >= 0.9995
+        if tri is not None:
+            ok = ok and (tri[y, x] == g["tri"]).mean() >= 0.9999
     return bool(ok)
 
 
@@ -304,6 +317,7 @@ def main():
     m, lights = host.read_camera_sav(os.path.join(ROOT, "scenes", "cameras", SCENE + ".sav"))
     corners = host.camera_corners(m, W, H)
     p = capi.default_params(W, H, MSAA)
+    frame_params = capi.default_params(W, H, MSAA)   # the whole frame; p carries this rank's part of the deal
     p.tile_w = p.tile_h = TILE
     L = capi.lib()
 
@@ -317,11 +331,16 @@ def main():
     # Whether two launches really overlap depends on the hardware queues the runtime gave their streams
     # (not visible to a program): with two frames in flight, four candidates are made and, once the
     # deal is settled, the partner of the first is the one whose launches are seen to overlap its own.
-    n_flight = args.frames_in_flight or (1 if world == 1 else 2)
-    n_cand = 4 if n_flight == 2 else n_flight
+    # The line's value and ms_per_step come from a timed loop with ONE frame in flight, for every N, so that
+    # the values the driver divides for its scaling curve are of one kind (the time of a frame); a second
+    # timed loop of the same K steps with two frames in flight follows and is reported beside it
+    # ("two_frames_in_flight": throughput of consecutive frames).  --frames-in-flight F runs the first loop
+    # with F instead (experiments).
+    n_flight = args.frames_in_flight or 1
+    n_cand = 4
     slots = []
     for i in range(n_cand):
-        st_ = torch.cuda.Stream(device=dev) if n_flight > 1 else torch.cuda.current_stream()
+        st_ = torch.cuda.Stream(device=dev)
         slots.append({"gs": hs.to_gpu(local), "stream": st_,
                       "rgb": torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
                       "depth": torch.zeros((H, W), dtype=torch.float32, device=dev),
@@ -353,29 +372,32 @@ def main():
             comm = C.c_void_p()
 
     def set_deal(first_rank_shares):
-        """Tiles are dealt over n_shares = first_rank_shares + 16 (N - 1) shares; rank r renders
-        `span` consecutive ones (RtParams.rank / world / rank_span)."""
-        n_shares, deal = pkg.tiles.shares(world, first_rank_shares / PER_RANK, PER_RANK)
-        p.rank, p.rank_span = deal[rank]
-        p.world = n_shares
+        """The library's deal (rt_deal_params): tiles go over first_rank_shares + 16 (N - 1) shares, rank 0
+        renders the first first_rank_shares of them, every other rank 16."""
+        per = []
+        for r in range(world):
+            pr = capi.RtParams()
+            capi.check(L.rt_deal_params(C.byref(frame_params), world, first_rank_shares, r, C.byref(pr)))
+            per.append(pr)
+        p.tile_w, p.tile_h = per[rank].tile_w, per[rank].tile_h
+        p.rank, p.world, p.rank_span = per[rank].rank, per[rank].world, per[rank].rank_span
         n_slots = L.rt_tile_pixels(C.byref(p), p.rank)
-        state.update(deal=(n_shares, deal), first_rank_shares=deal[0][1])
-        per_rank = []
-        for first, span in deal:
-            pr = capi.RtParams.from_buffer_copy(p)
-            pr.rank, pr.rank_span = first, span
-            per_rank.append(int(L.rt_tile_pixels(C.byref(pr), pr.rank)) * 4)
+        state.update(deal=(per[0].world, [(q.rank, q.rank_span) for q in per]), first_rank_shares=first_rank_shares)
+        per_rank = [int(L.rt_tile_pixels(C.byref(q), q.rank)) * 4 for q in per]
         state["floats_per_rank"] = (C.c_int64 * world)(*per_rank)
         state["offsets"] = [sum(per_rank[:r]) for r in range(world)]
         for sl in slots:
+            capi.check(L.rt_scene_set_deal(sl["gs"].h, first_rank_shares))
             sl["payload"] = torch.zeros((max(n_slots, 1), 4), dtype=torch.float32, device=dev)[:n_slots]
             sl["gathered"] = torch.zeros(max(sum(per_rank), 4) if rank == 0 else 4, dtype=torch.float32,
                                          device=dev)
 
     set_deal(PER_RANK)
 
+    flight = {"n": n_flight}
+
     def frame(i=0, stats=False):
-        sl = slots[i % n_flight]
+        sl = slots[i % flight["n"]]
         with torch.cuda.stream(sl["stream"]):
             stream = sl["stream"].cuda_stream
             d_rgb, d_depth = C.c_void_p(sl["rgb"].data_ptr()), C.c_void_p(sl["depth"].data_ptr())
@@ -445,7 +467,18 @@ def main():
     # fraction is f0 = (1 - (N - 1) * t_post / A) / N; A comes from rank 0's render time under
     # two deals (equal shares, half shares).
     calib = None
-    if world > 1 and os.environ.get("RT_BENCH_EVEN") != "1":
+    if world > 1 and os.environ.get("RT_BENCH_EVEN") != "1" and state["gather"] == "rt_gather_tiles_rccl":
+        # the library's own calibration (rt_calibrate_deal, what rt_render --gpus N runs): a collective call
+        got = C.c_int32(0)
+        cam_ = np.ascontiguousarray(corners, np.float32)
+        li_ = np.ascontiguousarray(lights, np.float32)
+        capi.check(L.rt_calibrate_deal(gs.h, comm, rank, world, cam_.ctypes.data_as(C.c_void_p),
+                                       li_.ctypes.data_as(C.c_void_p), len(li_), C.byref(frame_params),
+                                       C.byref(got)))
+        set_deal(int(got.value))
+        calib = {"by": "rt_calibrate_deal", "first_rank_shares": int(got.value)}
+    elif world > 1 and os.environ.get("RT_BENCH_EVEN") != "1":
+        # without a communicator of the library's (rehearsal over gloo, torch's gather): the same rule here
         frame()                                        # first-touch allocations
         t_eq, t_post = timed_frames(2)
         f_eq = PER_RANK / state["deal"][0]
@@ -460,7 +493,7 @@ def main():
                 f0 = (1.0 - (world - 1) * (t_post + 0.1) / slope) / world   # + 0.1 ms for the unpack kernels
                 f0 = min(max(f0, 0.2 / world), 1.0 / world)
                 shares0 = int(round(PER_RANK * (world - 1) * f0 / (1.0 - f0)))
-            calib = {"render_ms_equal": round(t_eq, 3), "render_ms_half": round(t_half, 3),
+            calib = {"by": "bench.py", "render_ms_equal": round(t_eq, 3), "render_ms_half": round(t_half, 3),
                      "post_ms": round(t_post, 3)}
         shares0 = bcast_int(min(max(shares0, 1), PER_RANK))
         set_deal(shares0)
@@ -481,7 +514,7 @@ def main():
             "torch.distributed.gather (rt_gather_tiles_rccl rebuilt a different frame)"
 
     flight_probe = None
-    if n_cand > n_flight:
+    if True:
         def part_ms(which, n=12):
             for rep_ in range(2):                       # the first pass warms up
                 torch.cuda.synchronize()
@@ -516,28 +549,44 @@ def main():
             dist.all_reduce(my)
     rays_per_frame, tests_per_frame, nodes_per_frame = (float(x) for x in my.tolist())
 
-    for i in range(args.warmup):
-        frame(i)
-    for sl in slots:
-        sl["gs"].set_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        frame(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kt = capi.RtKernelTimes()
-    for sl in slots:
-        k_ = sl["gs"].collect_timing()
-        kt.frame_ms += k_.frame_ms
-        kt.frames += k_.frames
-        sl["gs"].set_timing(False)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        if backend == "gloo":
-            el = el.cpu()
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    def timed_loop(n_in_flight):
+        """W untimed steps, then exactly K steps between barriers: seconds (max over ranks) and the HIP-event
+        times of this rank's launches inside the timed region."""
+        flight["n"] = n_in_flight
+        for i in range(args.warmup):
+            frame(i)
+        for sl in slots:
+            sl["gs"].set_timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            frame(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        kt_ = capi.RtKernelTimes()
+        for sl in slots:
+            k_ = sl["gs"].collect_timing()
+            kt_.frame_ms += k_.frame_ms
+            kt_.frames += k_.frames
+            sl["gs"].set_timing(False)
+        el = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            if backend == "gloo":
+                el = el.cpu()
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), kt_
+
+    elapsed, kt = timed_loop(n_flight)
+    other_flight = 2 if n_flight == 1 else 1
+    elapsed_other, kt_other = timed_loop(other_flight)
+    flight["n"] = n_flight
+    # the second slot holds a whole frame of its own once a loop has given it one (bit patterns: the blurred
+    # plane holds the reference's NaN pixel)
+    slot1_used = args.steps >= 2 or args.warmup >= 2
+    two_equal_one = True
+    if rank == 0 and slot1_used:
+        two_equal_one = all(bool(torch.equal(slots[0][k_].view(torch.int32), slots[1][k_].view(torch.int32)))
+                            for k_ in ("rgb", "depth", "blurred"))
 
     if rank == 0 and world > 1 and os.environ.get("RT_BENCH_CHECK") == "1":
         # rehearsal check: the gathered frame equals the frame one GPU renders alone
@@ -546,7 +595,7 @@ def main():
         depth1 = torch.zeros_like(depth)
         gs.render_device(corners, lights, p1, rgb1.data_ptr(), depth1.data_ptr(), 0, 0, False)
         torch.cuda.synchronize()
-        same = all(bool((rgb1 == sl["rgb"]).all().item()) for sl in slots[:max(1, min(n_flight, args.steps))])
+        same = all(bool((rgb1 == sl["rgb"]).all().item()) for sl in slots[:2 if slot1_used else 1])
         print(f"partition check: gathered frame {'equals' if same else 'DIFFERS FROM'} the single-GPU frame",
               file=sys.stderr, flush=True)
         if not same:
@@ -555,7 +604,7 @@ def main():
     if rank == 0:
         # outside the timed region: the frame the loop produced last, against the oracle's fixtures
         torch.cuda.synchronize()
-        last = slots[(args.steps - 1) % n_flight] if args.steps > 0 else slots[0]
+        last = slots[0]      # (the second loop's frames alternate between the two slots: compared above)
         h_rgb, h_depth1 = last["rgb"].cpu().numpy(), last["depth"].cpu().numpy()
         raw = torch.zeros_like(last["depth"])               # the depth plane before normalisation
         p1 = capi.default_params(W, H, MSAA)
@@ -567,10 +616,11 @@ def main():
         from oracle import oracle as O
         ok_depth = bool(np.array_equal(O.normalize_depth(raw.cpu().numpy(), p.focusDepth), h_depth1))
         ok_blur = check_blur(h_rgb, h_depth1, last["blurred"].cpu().numpy(), p.focusDepth, p.depthPower)
-        checked = bool(same_rgb and ok_sparse and ok_depth and ok_blur)
+        checked = bool(same_rgb and ok_sparse and ok_depth and ok_blur and two_equal_one)
         if not checked:
             print(f"bench check FAILED: frame equals a fresh render {same_rgb}, sparse pixels {ok_sparse}, "
-                  f"depth normalisation {ok_depth}, blur {ok_blur}", file=sys.stderr, flush=True)
+                  f"depth normalisation {ok_depth}, blur {ok_blur}, both slots hold the same frame {two_equal_one}",
+                  file=sys.stderr, flush=True)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = rays_per_frame * args.steps / elapsed / 1e6
@@ -579,6 +629,19 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "checked": checked,
+            # a line from one GPU says nothing about scaling; no multi-GPU node has run this bench yet
+            "scaling_measured": world > 1,
+            "frames_in_flight": n_flight,
+            ("two_frames_in_flight" if other_flight == 2 else "one_frame_in_flight"): {
+                "ms_per_step": round(elapsed_other / args.steps * 1e3, 3),
+                "value": round(rays_per_frame * args.steps / elapsed_other / 1e6, 2),
+                "k_wf_pipeline_ms": round(kt_other.frame_ms / max(kt_other.frames, 1), 3),
+                "what": "the same K steps timed again with %d frame%s in flight per GPU (streams, workspaces and "
+                        "frame buffers of their own): %s; the line's value and ms_per_step are the loop with %d"
+                        % (other_flight, "s" if other_flight > 1 else "",
+                           "throughput of consecutive frames, the launch of frame i + 1 fills the GPU as the last "
+                           "regions of frame i run out" if other_flight == 2 else "the time of one frame", n_flight)},
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "data": "scenes/final.obj + scenes/cameras/final.sav (the reference's own scene; no "
                     "published camera exists, this one is fixed in the repo)",
             "config": {"workload": f"{SCENE}.obj {W}x{H} MSAA{MSAA} + DoF, {len(lights)} lights, "
@@ -675,7 +738,6 @@ def main():
                               for n_, w_, h_, m_ in OTHER_CONFIGS}
             out["r_path_ms"] = r_path_ms(pkg, local)
             out["frame_parts_in_flight"] = frame_parts_in_flight(pkg, hs, corners, lights, local)
-            out["whole_frames_in_flight"] = frame_parts_in_flight(pkg, hs, corners, lights, local, parts=1, frames=16)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corners, lights)
         print(json.dumps(out), flush=True)

@@ -292,16 +292,49 @@ void rt_rccl_comm_destroy(void *comm);
 int  rt_gather_tiles_rccl(void *comm, int32_t rank, int32_t n_ranks, const float *d_payload,
                           const int64_t *floats_per_rank, float *d_gathered, void *stream);
 
+/* The deal of a shared frame.  The reference gives every thread an equal band of rows and lets a
+ * thread that is through steal rows from the others (main.cpp:329-339, 410-429); here the tiles are
+ * dealt once, unevenly: 32 x 32 tiles go round-robin over first_rank_shares + RT_SHARES_PER_RANK *
+ * (n_ranks - 1) shares, rank 0 renders the first first_rank_shares of them (1..RT_SHARES_PER_RANK: it
+ * also unpacks the gathered tiles and runs the post-process), every other rank RT_SHARES_PER_RANK.
+ * rt_deal_params: `frame` with tile size, rank, world and rank_span filled in for `rank` of that deal
+ *   (what rt_render_frame_device, rt_tile_pixels and the pack / unpack calls take).
+ * rt_scene_set_deal: the first_rank_shares later rt_render_result_planes_shared calls on this scene
+ *   use (RT_SHARES_PER_RANK, an even deal, until it is set); every rank must set the same value.
+ * rt_calibrate_deal: measures and sets it, a collective call of all ranks before the frames that
+ *   count.  Rank 0 times its render under an even deal and under a halved share (time = slope * share
+ *   of the frame + tail), renders the whole frame once to time its post-process on it, and takes the
+ *   share f0 = (1 - (n_ranks - 1) * (t_post + 0.1 ms) / slope) / n_ranks, clamped to [0.2, 1] / n_ranks;
+ *   the result travels to the other ranks over the communicator.  Returns it in *first_rank_shares. */
+#define RT_SHARES_PER_RANK 16
+int rt_deal_params(const RtParams *frame, int32_t n_ranks, int32_t first_rank_shares, int32_t rank,
+                   RtParams *out);
+int rt_scene_set_deal(RtScene *scene, int32_t first_rank_shares);
+int rt_calibrate_deal(RtScene *scene, void *comm, int32_t rank, int32_t n_ranks, const float camera[24],
+                      const float *lights, int32_t n_lights, const RtParams *params,
+                      int32_t *first_rank_shares);
+
 /* rt_render_result_planes for a frame shared by n_ranks processes, one per GPU (the C++ host's
- * replacement of the thread bands of main.cpp:329-339): this rank renders its 32 x 32 tiles
- * (dealt round-robin, tile t to rank t % n_ranks), the payloads are gathered on rank 0
- * (rt_gather_tiles_rccl), and rank 0 rebuilds the frame, post-processes it and receives the
- * planes; on the other ranks the three pointers come back NULL.  n_ranks == 1 needs no
- * communicator.  Every rank calls it with the same camera, lights and params. */
+ * replacement of the thread bands of main.cpp:329-339): this rank renders its tiles of the scene's
+ * deal (above), the payloads are gathered on rank 0 (rt_gather_tiles_rccl), and rank 0 rebuilds the
+ * frame, post-processes it and receives the planes; on the other ranks the three pointers come
+ * back NULL.  n_ranks == 1 needs no communicator.  Every rank calls it with the same camera,
+ * lights and params. */
 int rt_render_result_planes_shared(RtScene *scene, void *comm, int32_t rank, int32_t n_ranks,
                                    const float camera[24], const float *lights, int32_t n_lights,
                                    const RtParams *params, const uint8_t **rgb8, const uint8_t **depth8,
                                    const uint8_t **blurred8, RtStats *stats);
+
+/* The shared frame rehearsed on ONE GPU: the parts of all n_ranks ranks of the scene's deal are
+ * rendered here one after the other, each but rank 0's into a frame of its own, packed, laid out as
+ * the gather would lay them out, unpacked into rank 0's frame and post-processed - every step of
+ * rt_render_result_planes_shared but the transfer, for machines with fewer GPUs than ranks.  The
+ * planes equal those of rt_render_result_planes byte for byte (a frame does not depend on its
+ * partition). */
+int rt_render_result_planes_rehearsal(RtScene *scene, int32_t n_ranks, const float camera[24],
+                                      const float *lights, int32_t n_lights, const RtParams *params,
+                                      const uint8_t **rgb8, const uint8_t **depth8,
+                                      const uint8_t **blurred8, RtStats *stats);
 
 #ifdef __cplusplus
 }

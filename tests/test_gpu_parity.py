@@ -78,6 +78,18 @@ def test_trace_rays_untextured_match_reference(oracle, name):
     assert (diff <= 1).mean() >= 0.999
 
 
+def test_rays_on_which_the_reference_never_returns(oracle):
+    """The two rays of lego.obj at 4K MSAA 4 on which the reference's unbounded leaf walk does not end
+    (fixture walk_guard_lego.npz records that the real reference did not return): the stack walk has no
+    such state and returns the closest hit over all triangles, bit for bit."""
+    g = load_golden("walk_guard_lego")
+    gs = pkg().host.HostScene(os.path.join(SCENES, "lego.obj")).to_gpu(0)
+    tri, a, b, t, hp = gs.check_hits(g["origins"], g["dests"])
+    assert np.array_equal(tri, g["brute_tri"]) and np.array_equal(t, g["brute_t"])
+    rgb, mt, tri2, _ = gs.trace_rays(g["origins"], g["dests"], np.float32([[0, 10, 0], [4, 6, 5]]))
+    assert np.array_equal(tri2, g["brute_tri"]) and np.array_equal(mt, g["brute_t"]) and np.isfinite(rgb).all()
+
+
 @pytest.mark.parametrize("name", ["lego", "final"])
 def test_trace_rays_textured_match_reference(oracle, name):
     """The same rays with the scenes' textures: colours the reference's own Material::getTexture

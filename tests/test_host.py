@@ -227,6 +227,30 @@ def test_uneven_deal_covers_every_pixel_once(P, W, H, n_ranks, w0):
     assert P.capi.lib().rt_tile_pixels(C.byref(p), 0) == -1
 
 
+@pytest.mark.parametrize("W,H,n_ranks,first", [(64, 48, 2, 8), (100, 70, 3, 5), (3840, 2160, 8, 11), (200, 40, 4, 1),
+                                                 (96, 96, 2, 16), (50, 50, 1, 16)])
+def test_library_deal_covers_every_pixel_once(P, W, H, n_ranks, first):
+    """rt_deal_params - the deal rt_render_result_planes_shared and rt_calibrate_deal use (rank 0 renders
+    `first` of 16 shares per GPU) - equals tiles.shares, and its parts cover the frame exactly once."""
+    L = P.capi.lib()
+    frame = P.capi.default_params(W, H)
+    world, deal = P.tiles.shares(n_ranks, first / 16, per_rank=16)
+    seen = np.zeros((H, W), np.int32)
+    for r in range(n_ranks):
+        p = P.capi.RtParams()
+        assert L.rt_deal_params(C.byref(frame), n_ranks, first, r, C.byref(p)) == 0
+        assert (p.rank, p.rank_span) == (deal[r] if n_ranks > 1 else (0, 1)) and p.world == world
+        assert (p.tile_w, p.tile_h, p.width, p.height) == (32, 32, W, H)
+        x, y, ok = P.tiles.slot_pixels(W, H, 32, 32, p.rank, p.world, p.rank_span)
+        assert L.rt_tile_pixels(C.byref(p), p.rank) == len(x)
+        np.add.at(seen, (y[ok], x[ok]), 1)
+    assert (seen == 1).all()
+    p = P.capi.RtParams()
+    for bad in ((0, first, 0), (n_ranks, 0, 0), (n_ranks, 17, 0), (n_ranks, first, n_ranks), (n_ranks, first, -1)):
+        assert L.rt_deal_params(C.byref(frame), bad[0], bad[1], bad[2], C.byref(p)) == -1
+    assert L.rt_scene_set_deal(None, 8) == -1
+
+
 def test_tile_pack_unpack_roundtrip(P):
     rng = np.random.default_rng(5)
     W, H = 70, 50

@@ -218,3 +218,23 @@ def test_full_size_textured_pixels_equal_reference(oracle, name, W, H):
     px = (acc / np.float32(4)).astype(np.float32)
     px[tri[0] < 0] = rgb[0][tri[0] < 0]
     assert np.array_equal(np.clip(px, 0, 1), r["rgb"][:n])
+
+
+def test_rays_on_which_the_reference_never_returns(oracle):
+    """Decision D7: the two rays of lego.obj 3840x2160 MSAA 4 on which the reference's leaf walk
+    (raytracing.cpp:303-349 has no bound) steps between neighbouring leaves for ever - the fixture
+    records that the real reference did not return within 20 s on either (tools/make_guard_fixture.py).
+    The oracle stops the walk after 100000 steps, counts it, and keeps the closest hit found until
+    then, which is the closest hit over all triangles."""
+    g = load_golden("walk_guard_lego")
+    assert len(g["origins"]) == 2 and not g["reference_returns"].any() and int(g["frame_walks"]) == 2
+    s = oracle.Scene.load(os.path.join(SCENES, "lego.obj"))
+    oracle.guard_rays()
+    c = oracle.Counters()
+    tri, a, b, t, hp = s.check_hits(g["origins"], g["dests"], counters=c)
+    assert c.walk_guard == 2 and c.leaf_steps > 200000
+    assert np.array_equal(oracle.guard_rays()[:, :3], g["origins"])
+    assert np.array_equal(tri, g["oracle_tri"]) and np.array_equal(t, g["oracle_t"])
+    btri, bt = s.brute_hits(g["origins"], g["dests"])
+    assert np.array_equal(tri, btri) and np.array_equal(t, bt)
+    assert np.array_equal(btri, g["brute_tri"]) and np.array_equal(bt, g["brute_t"])
