@@ -119,7 +119,8 @@ def cpu_baseline(corners, lights):
 
 
 OTHER_CONFIGS = [("ball", 800, 800, 1), ("redballs", 1920, 1080, 1), ("refractionballs", 1920, 1080, 1),
-                 ("lego", 3840, 2160, 4)]
+                 ("lego", 3840, 2160, 4),
+                 ("fin", 1920, 1080, 1)]   # not a BASELINE config: the reference's largest scene, with refraction
 
 
 def r_path_ms(pkg, dev_index):
@@ -207,7 +208,8 @@ def config_record(pkg, name, w, h, msaa, fc, dev_index, frames=5):
     info = gs.info()
     rec = {"ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1), "rays_per_frame": int(rays),
            "lights": len(lights), "launches_timed": kt.frames,
-           "scene_create_ms": round(info["create_ms"], 2), "tree_steps_ms": round(info["tree_ms"], 2)}
+           "scene_create_ms": round(info["create_ms"], 2), "tree_steps_ms": round(info["tree_ms"], 2),
+           "device_nodes": info["n_nodes"], "render_path": info["render_path"]}
     if fc.get(key):
         f_needed = fc[key].get("flops_needed", fc[key]["flops_frame"])
         rec["frac"] = round(f_needed / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)

@@ -140,7 +140,10 @@ typedef struct RtSceneInfo {
     float    create_ms;  /* wall time of rt_scene_create */
     float    tree_ms;    /* of which: handing triangles down + splitting leaves */
     int32_t  tree_on_gpu; /* 1: those two steps ran on the device, 0: on the host (RT_KD_GPU=0) */
-    int32_t  reserved;
+    int32_t  render_path; /* what rt_render_frame* runs for this scene: 0 the single persistent launch over ray
+                           * queues (the product path), 1 the same stages as one launch each
+                           * (RT_WF_MULTILAUNCH=1), 2 one thread per camera sample (RT_MEGAKERNEL=1 or
+                           * RT_KD_PUSHDOWN=0: ablation switches; an order of magnitude slower) */
 } RtSceneInfo;
 
 /* Per-kernel device time of the render calls since timing was switched on or

@@ -76,7 +76,7 @@ class RtSceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_triangles", C.c_int32), ("tree_depth", C.c_int32),
                 ("n_slots", C.c_int32), ("device_bytes", C.c_uint64), ("tree_hash", C.c_uint64),
                 ("create_ms", C.c_float), ("tree_ms", C.c_float), ("tree_on_gpu", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("render_path", C.c_int32)]
 
 
 EXPORTS = [

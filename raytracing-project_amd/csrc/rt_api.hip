@@ -931,7 +931,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
             prm.mesh_box.lo[a] = lo[a] - pad, prm.mesh_box.hi[a] = hi[a] + pad;
         }
-        const size_t max_nodes = 60000; // node indices are 16-bit on the traversal stack
+        const size_t max_nodes = (size_t)1 << 22; // (a node names its left child in 30 bits)
         // Both steps run on the device (rt_kdrefine.h); RT_KD_GPU=0, or a triangle pool that
         // overflows, leaves them to the host loops below, which produce the same tree.
         const char* kg_env = getenv("RT_KD_GPU");
@@ -1217,6 +1217,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
     for (int i = 0; i < nm; ++i) // raytracing.cpp:177,206: two children only if Ni > 1 and not a mirror
         if (desc->materials[i].Ni > 1.0f && desc->materials[i].illum != 3) s->refractive = true;
+    if (!(s->pushdown && !s->cfg.megakernel)) // never silently: the frame path of this scene is the slow one
+        fprintf(stderr, "rt_scene_create: RT_MEGAKERNEL / RT_KD_PUSHDOWN=0 set - frames of this scene render with one "
+                        "thread per camera sample, not with the ray-queue pipeline\n");
     *out = s;
     return RT_OK;
 }
@@ -1231,7 +1234,8 @@ extern "C" int rt_scene_info(const RtScene* s, RtSceneInfo* info)
     info->device_bytes = s->bytes;
     info->tree_hash = s->tree_hash;
     info->create_ms = s->create_ms, info->tree_ms = s->tree_ms;
-    info->tree_on_gpu = s->tree_on_gpu, info->reserved = 0;
+    info->tree_on_gpu = s->tree_on_gpu;
+    info->render_path = (s->pushdown && !s->cfg.megakernel) ? (s->cfg.multilaunch ? 1 : 0) : 2;
     return RT_OK;
 }
 
@@ -1465,7 +1469,7 @@ static int ensure_workspace(RtScene* s, long long n_slots, int msaa)
 // Traversal stack entries per thread kept in LDS.  Measured per 4K frame: 10.59 / 10.53 / 10.55 / 10.69 ms
 // with 12 / 10 / 8 / 6; six leave room for the colour sums of a region of 512 samples beside
 // them at seven blocks per CU (seven entries: six blocks, 10.8 vs 10.3 ms).
-#define WF_STACK_LDS 6
+#define WF_STACK_LDS 5
 #define WF_ACC_SAMPLES 512 // samples per region the single launch holds colour sums for (24 bytes each, LDS)
 #define WF_WORKSPACE_BUDGET ((size_t)12 << 30) // bytes of queues per scene at most
 
@@ -1496,9 +1500,8 @@ static int wf_prepare(RtScene* s)
     const size_t deep = (size_t)(s->d.stack_entries - cap);
     const size_t blocks = (size_t)std::max(g_trace, std::max(g_any, g_pipe));
     const size_t n_deep = std::max<size_t>(deep * blocks * WF_BLOCK, 64);
-    HIP_TRY(hipMalloc(&s->d_stk_spill, n_deep * WF_STACK_ENTRY_BYTES)); // floats first, then the node indices
-    s->d.stk_spill_t = (float*)s->d_stk_spill;
-    s->d.stk_spill = (unsigned short*)((float*)s->d_stk_spill + n_deep);
+    HIP_TRY(hipMalloc(&s->d_stk_spill, n_deep * WF_STACK_ENTRY_BYTES));
+    s->d.stk_spill = (uint2*)s->d_stk_spill;
     s->wf_grid_trace = g_trace, s->wf_grid_any = g_any, s->wf_grid_pipe = g_pipe;
     s->wf_cus = prop.multiProcessorCount;
     return RT_OK;
@@ -1789,7 +1792,7 @@ extern "C" int rt_render_frame_device(RtScene* s, const float camera[24], const 
     if (stats) memset(stats, 0, sizeof *stats);
     HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
-    const bool wavefront = s->pushdown && s->d.n_nodes < 65536 && !s->cfg.megakernel;
+    const bool wavefront = s->pushdown && !s->cfg.megakernel;
     if (n_slots > 0 && wavefront) {
         if ((rc = render_wavefront(s, P, n_slots, d_rgb, d_depth, d_tri, stream, stats != nullptr))) return rc;
     } else if (n_slots > 0) {

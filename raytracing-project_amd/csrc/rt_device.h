@@ -58,9 +58,8 @@ struct DScene {
     const int32_t* tri_rank;  // per original triangle: order in which the reference's walk tests it
     int32_t        n_nodes, n_slots, n_triangles, stack_entries;
     // wavefront traversal stack: the first stk_cap entries of a thread live in LDS, deeper
-    // ones in stk_spill / stk_spill_t (per block: [entry - stk_cap][thread])
-    unsigned short* stk_spill;
-    float*          stk_spill_t;
+    // ones in stk_spill (per block: [entry - stk_cap][thread]); an entry is (node, bits of the entry t)
+    uint2*          stk_spill;
     int32_t         stk_cap;
     float           vert_l1; // largest |x| + |y| + |z| over the vertices (tri_head_keep's bound on n . v2)
 };

@@ -157,50 +157,48 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int pa
     if (threadIdx.x == 1023) out[n] = s_part[1023];
 }
 
-// Per-thread traversal stack.  An entry is the far child still to be visited (16-bit node
-// index) and the ray parameter at which the ray enters it.  Entry e of a thread sits at
-// index e * WF_BLOCK of the LDS arrays while e < cap, else at (e - cap) * WF_BLOCK of the
-// spill arrays in HBM.  Rays rarely have more than a dozen far children pending, so a short
-// LDS part serves nearly all pushes and pops while the tree's full depth stays available;
-// LDS per block, and with it the number of resident waves, does not grow with the depth of
-// the tree.
+// Per-thread traversal stack.  An entry is the far child still to be visited (node index) and the
+// ray parameter at which the ray enters it, eight bytes written and read as one.  Entry e of a
+// thread sits at index e * WF_BLOCK of the LDS array while e < cap, else at (e - cap) * WF_BLOCK of
+// the spill array in HBM.  Rays rarely have more than a handful of far children pending, so a short
+// LDS part serves nearly all pushes and pops while the tree's full depth stays available; LDS per
+// block, and with it the number of resident waves, does not grow with the depth of the tree.
+// (Until the node index took 32 bits the entry was a 16-bit node beside a float in two arrays: two
+// LDS instructions and two addresses per push, and no scene beyond 65535 nodes on this path.)
 struct WfStack {
-    unsigned short* lds_node;
-    float*          lds_t;
-    unsigned short* spill_node;
-    float*          spill_t;
-    int             cap;
+    uint2* lds;
+    uint2* spill;
+    int    cap;
 };
 
-// LDS layout per block: float t[cap][WF_BLOCK], then ushort node[cap][WF_BLOCK]
-#define WF_STACK_ENTRY_BYTES 6
+// LDS layout per block: uint2 entry[cap][WF_BLOCK]
+#define WF_STACK_ENTRY_BYTES 8
 
 __device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_mem)
 {
     WfStack k;
     k.cap = S.stk_cap;
-    k.lds_t = (float*)s_mem + threadIdx.x;
-    k.lds_node = (unsigned short*)(s_mem + (size_t)k.cap * WF_BLOCK * sizeof(float)) + threadIdx.x;
+    k.lds = (uint2*)s_mem + threadIdx.x;
     const size_t deep = (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK;
-    k.spill_t = S.stk_spill_t + (size_t)blockIdx.x * deep + threadIdx.x;
-    k.spill_node = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
+    k.spill = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
     return k;
 }
 
 __device__ __forceinline__ void wf_stk_put(const WfStack& k, int e, int node, float t)
 {
-    if (e < k.cap) k.lds_node[e * WF_BLOCK] = (unsigned short)node, k.lds_t[e * WF_BLOCK] = t;
-    else k.spill_node[(size_t)(e - k.cap) * WF_BLOCK] = (unsigned short)node, k.spill_t[(size_t)(e - k.cap) * WF_BLOCK] = t;
+    const uint2 v = make_uint2((unsigned)node, __float_as_uint(t));
+    if (e < k.cap) k.lds[e * WF_BLOCK] = v;
+    else k.spill[(size_t)(e - k.cap) * WF_BLOCK] = v;
 }
 
-__device__ __forceinline__ int wf_stk_node(const WfStack& k, int e)
+__device__ __forceinline__ uint2 wf_stk_get(const WfStack& k, int e)
 {
-    return e < k.cap ? k.lds_node[e * WF_BLOCK] : k.spill_node[(size_t)(e - k.cap) * WF_BLOCK];
+    return e < k.cap ? k.lds[e * WF_BLOCK] : k.spill[(size_t)(e - k.cap) * WF_BLOCK];
 }
 
 __device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
 {
-    return e < k.cap ? k.lds_t[e * WF_BLOCK] : k.spill_t[(size_t)(e - k.cap) * WF_BLOCK];
+    return __uint_as_float(e < k.cap ? k.lds[e * WF_BLOCK].y : k.spill[(size_t)(e - k.cap) * WF_BLOCK].y);
 }
 
 // Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray over the compact node
@@ -338,9 +336,10 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         bool found = false;
         while (sp > 0) {
             --sp;
-            const float et = wf_stk_t(stk, sp);
+            const uint2 top = wf_stk_get(stk, sp);
+            const float et = __uint_as_float(top.y);
             if (!ANY && et * (1.0f - RT_TRAV_EPS) > minT) continue;
-            node = wf_stk_node(stk, sp);
+            node = (int)top.x;
             tmin_e = et * (1.0f - RT_TRAV_EPS);
             tmax_e = sp > 0 ? wf_stk_t(stk, sp - 1) * (1.0f + RT_TRAV_EPS) : RT_FLT_MAX;
             found = true;

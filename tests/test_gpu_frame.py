@@ -38,15 +38,35 @@ def test_scene_info(P):
     # the device tree = the reference's 891 nodes / depth 20, refined below its leaves
     assert i["n_triangles"] == 3846 and i["n_nodes"] >= 891 and 20 <= i["tree_depth"] <= 63
     assert i["n_slots"] >= 3846          # straddling triangles are listed by every leaf they touch
-    assert i["device_bytes"] > 3846 * 48
+    assert i["device_bytes"] > 3846 * 64
+    assert i["render_path"] == 0         # the single persistent launch over ray queues
+
+
+def test_scene_beyond_65535_nodes_renders_on_the_pipeline(P, oracle):
+    """fin.obj (13444 triangles): its refined device tree has more nodes than a 16-bit index names;
+    traversal stack entries carry 32-bit nodes, so the scene stays on the ray-queue pipeline, with
+    its refinement run to the end.  A reduced frame against the oracle, refraction included."""
+    hs, gs, m, lights = _host_gpu(P, "fin")
+    i = gs.info()
+    assert i["n_nodes"] > 65535 and i["render_path"] == 0 and i["n_triangles"] == 13444
+    W, H = 240, 135
+    corners = P.host.camera_corners(m, W, H)
+    rgb, depth, tri, st = gs.render(corners, lights, P.capi.default_params(W, H, 4))
+    s = oracle.Scene.load(os.path.join(SCENES, "fin.obj"))
+    s.set_lights(lights)
+    s.settings.MSAA = 4
+    orgb, odepth, otri = s.render(corners, W, H, threads=8)
+    assert (tri == otri).mean() >= 0.9999
+    d = np.abs(oracle.to_bytes(rgb).astype(int) - oracle.to_bytes(orgb).astype(int)).max(axis=2)
+    assert (d <= 1).mean() >= 0.999
+    assert st.child_rays > 0
 
 
 @pytest.mark.parametrize("name", ["ball", "redballs", "lego", "final", "fin", "checkercube"])
 def test_tree_built_on_the_gpu_equals_the_host_built_one(P, monkeypatch, name):
     """rt_scene_create hands the inner nodes' triangles down and splits large leaves on the
     device; RT_KD_GPU=0 runs the same two steps as host loops.  The device tree must be the same
-    one: equal hash over nodes and slots, equal sizes - also with the refinement switched off,
-    and for fin.obj, where the node budget ends the splitting."""
+    one: equal hash over nodes and slots, equal sizes - also with the refinement switched off."""
     hs = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
     for env in ({}, {"RT_KD_REFINE": "0"}):
         infos = {}
@@ -335,7 +355,9 @@ def test_full_size_frames_against_sparse_fixture(P, oracle, key):
     if cfg["msaa"] == 1:
         # (a hit the reference's walk steps past, KDtree.cpp:288-587, changes a ray tree here and there)
         assert abs(st.rays_closest - cfg["frame"]["rays_closest"]) <= 1e-4 * cfg["frame"]["rays_closest"]
-        assert 0.4 * cfg["frame"]["rays_shadow"] <= st.rays_shadow <= cfg["frame"]["rays_shadow"]
+        # the shadow queries left out are the ones the oracle counts as unable to change shadowMax
+        needed = cfg["frame"]["rays_shadow"] - cfg["frame"]["moot_shadow_rays"]
+        assert abs(st.rays_shadow - needed) <= 1e-3 * needed and st.rays_shadow <= cfg["frame"]["rays_shadow"]
 
 
 @pytest.mark.parametrize("key", sorted(FC))
@@ -364,7 +386,7 @@ def test_full_size_frames_against_the_reference(P, oracle, key):
         assert (np.abs(depth[y, x][both] - g["depth"][both]) <= 1e-6 * g["depth"][both]).mean() >= 0.9995
 
 
-@pytest.mark.parametrize("key", [k for k in sorted(FC) if FC[k]["scene"] in ("lego", "final")])
+@pytest.mark.parametrize("key", [k for k in sorted(FC) if FC[k]["scene"] in ("lego", "final", "fin")])
 def test_full_size_textured_frames_against_the_reference(P, oracle, key):
     """The two textured BASELINE configs at full size, WITH their textures, against the REAL reference:
     20000 seeded pixels whose camera rays went through the reference's performRayTracing with

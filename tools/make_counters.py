@@ -34,6 +34,9 @@ CONFIGS = [
     ("refractionballs", 1920, 1080, 1),
     ("lego", 3840, 2160, 4),
     ("final", 3840, 2160, 4),
+    # not a BASELINE config: the reference's largest scene (13444 triangles) and, besides refractionballs, the
+    # only one with a refractive material (fin.mtl:122-129); camera and lights of final.sav
+    ("fin", 1920, 1080, 1),
 ]
 
 
