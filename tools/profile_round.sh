@@ -1,12 +1,12 @@
 #!/bin/bash
 # Profiles of a round, on the GPU box: tools/profile_round.sh <tag> [passes]   (writes gpurun_out/prof_<tag>/)
-#   passes: any of "stats sq fetch write tcp tcc ta" (default: all)
+#   passes: any of "stats sq fetch write tcp tcc ta dram" (default: all)
 #   1. rocprofv3 --kernel-trace --stats around the default bench command (no CPU baseline, no extras)
 #   2. PMC passes around two frames of the headline config, one counter group per run
 # Every GPU step has its own time limit and the script stops at the first failure.
 set -e
 tag=${1:-run}
-passes=${2:-stats sq fetch write tcp tcc ta}
+passes=${2:-stats sq fetch write tcp tcc ta dram}
 want() { [[ " $passes " == *" $1 "* ]]; }
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -29,5 +29,8 @@ pmc write WRITE_SIZE
 pmc tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum
 pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc ta TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE
+python3 tools/pmc_digest.py $out > $out/digest.json
+# requests the L2 sends on towards DRAM, as opposed to all fabric requests (FETCH_SIZE / WRITE_SIZE count both)
+pmc dram TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum
 python3 tools/pmc_digest.py $out > $out/digest.json
 cat $out/digest.json
