@@ -478,6 +478,7 @@ struct RtScene {
     DScene  d{};
     void*   d_nodes = nullptr;
     void*   d_tris = nullptr;
+    void*   d_edges = nullptr;
     void*   d_shade = nullptr;
     void*   d_info = nullptr;
     void*   d_texcoords = nullptr;
@@ -580,7 +581,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
@@ -1051,7 +1052,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         depth_of.push_back(0);
     }
     std::vector<DNode>  nodes(lists.size());
-    std::vector<float4> slots;
+    std::vector<float4> slots, edges;
     for (size_t k = 0; k < lists.size(); ++k) {
         DNode     dn;
         const int axis = axis_of[k];
@@ -1085,6 +1086,29 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
                 hd = make_float4((float)(nrm[0] / B), (float)(nrm[1] / B), (float)(nrm[2] / B), (float)(kk / B));
                 if (!std::isfinite(hd.w)) hd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            // the edge record (tri_edges_keep): ga = (e2 x n) / n.n, gb = (n x e1) / n.n and their offsets, scaled so
+            // that no component exceeds 1, in double, rounded once; zero (never decides anything) beside a zero head
+            float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0, g2 = g0;
+            const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+            if ((hd.x != 0.0f || hd.y != 0.0f || hd.z != 0.0f) && nn > 0.0 && std::isfinite(nn)) {
+                double ga[3], gb[3], G = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    const int j = (c + 1) % 3, l = (c + 2) % 3;
+                    ga[c] = (a2[j] * nrm[l] - a2[l] * nrm[j]) / nn;
+                    gb[c] = (nrm[j] * a1[l] - nrm[l] * a1[j]) / nn;
+                    G = std::max(G, std::max(std::fabs(ga[c]), std::fabs(gb[c])));
+                }
+                const double sc = 1.0 / G;
+                if (G > 0.0 && std::isfinite(sc) && sc > 1e-30 && sc < 1e30) {
+                    double ka = 0.0, kb = 0.0;
+                    for (int c = 0; c < 3; ++c) ga[c] *= sc, gb[c] *= sc, ka -= ga[c] * (double)v2[c], kb -= gb[c] * (double)v2[c];
+                    g0 = make_float4((float)ga[0], (float)ga[1], (float)ga[2], (float)ka);
+                    g1 = make_float4((float)gb[0], (float)gb[1], (float)gb[2], (float)kb);
+                    g2 = make_float4((float)sc, 0.0f, 0.0f, 0.0f);
+                    if (!std::isfinite(g0.w) || !std::isfinite(g1.w)) g0 = g1 = g2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            edges.push_back(g0), edges.push_back(g1), edges.push_back(g2);
             slots.push_back(hd);
             slots.push_back(make_float4(e1x, e1y, e1z, e2x));
             slots.push_back(make_float4(e2y, e2z, v2[0], v2[1]));
@@ -1167,7 +1191,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         s->cfg.stack_lds = num("RT_WF_STACK_LDS"), s->cfg.budget_mb = num("RT_WF_BUDGET_MB");
     }
     int rc;
-    if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) ||
+    if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) || (rc = upload(&s->d_edges, edges, &s->bytes)) ||
         (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
         (rc = upload(&s->d_texcoords, texcoords, &s->bytes)) ||
         (rc = upload(&s->d_mats, mats, &s->bytes)) || (rc = upload(&s->d_texinfo, texinfo, &s->bytes)) ||
@@ -1184,6 +1208,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     }
     s->d.nodes = (const DNode*)s->d_nodes;
     s->d.tris = (const float4*)s->d_tris;
+    s->d.edges = (const float4*)s->d_edges;
     s->d.tri_shade = (const float4*)s->d_shade;
     s->d.tri_info = (const int4*)s->d_info;
     s->d.texcoords = (const float*)s->d_texcoords;
@@ -1361,7 +1386,23 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
         fprintf(stderr, "diag: leaf visits: %llu empty, %llu with triangles\n", d[2], d[3]);
         fprintf(stderr, "diag: triangle loop: %llu wave trips, %llu with a lane past the plane head (%.3f), %llu such lanes (%.3f of the tests)\n",
                 d[1] / 64, d[8], (double)d[8] / (double)(d[1] ? d[1] / 64 : 1), d[9], (double)d[9] / (double)(c.tri_tests ? c.tri_tests : 1));
+        fprintf(stderr, "diag: exact tests: %llu wave trips with a lane that hits (%.3f of the trips past the head), %llu such lanes (%.3f of the lanes past the head)\n",
+                d[12], (double)d[12] / (double)(d[8] ? d[8] : 1), d[13], (double)d[13] / (double)(d[9] ? d[9] : 1));
+        fprintf(stderr, "diag: edge records: %llu wave trips with a lane past them (%.3f of the trips past the head), %llu such lanes\n",
+                d[14], (double)d[14] / (double)(d[8] ? d[8] : 1), d[15]);
         fprintf(stderr, "diag: shadow rays %llu, occluded %llu, their tests %llu and node steps %llu\n", d[4], d[5], d[6], d[7]);
+    }
+#endif
+#ifdef WF_SECT
+    {
+        unsigned long long d[16] = {0}, z[16] = {0};
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_sect), sizeof d);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sect), z, sizeof z);
+        static const char* names[10] = {"take a batch", "form or fetch the ray", "closest-hit walk", "pixel-centre walk", "shading",
+                                        "fetch a shadow ray", "shadow walk", "report the answer", "wait at the barrier", "-"};
+        double sum = 0;
+        for (int i = 0; i < 10; ++i) sum += (double)d[i];
+        for (int i = 0; i < 9; ++i) fprintf(stderr, "sect: %-24s %6.2f %%  (%llu cycles over all waves)\n", names[i], 100.0 * (double)d[i] / (sum > 0 ? sum : 1), d[i]);
     }
 #endif
     float ms = 0;
@@ -1483,8 +1524,9 @@ static int wf_prepare(RtScene* s)
     // touched only by the rare ray with that many far children pending.
     int cap = s->cfg.stack_lds > 0 ? s->cfg.stack_lds : WF_STACK_LDS;
     cap = std::max(1, std::min(cap, (int)s->d.stack_entries));
+    if (cap < 2 && s->d.stack_entries >= 2) cap = 2; // a pop reads the two topmost entries with one instruction
     s->d.stk_cap = cap;
-    s->wf_lds = (size_t)cap * WF_BLOCK * WF_STACK_ENTRY_BYTES;
+    s->wf_lds = (size_t)cap * WF_BLOCK * WF_STACK_ENTRY_BYTES; // (a tree of one node never pushes: nothing is read)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;

@@ -49,6 +49,7 @@ struct DScene {
     const DNode*   nodes;
     const uint2*   knodes;
     const float4*  tris;
+    const float4*  edges;     // per slot: 3 float4 = (ga, ka) s, (gb, kb) s, (s, -, -, -), see tri_edges_keep
     const float4*  tri_shade; // per original triangle: 3 float4 = nA nB nC (xyz) + w: material, t0|t1.., see pack
     const int4*    tri_info;  // per original triangle: material, t0, t1, t2
     const float*   texcoords; // 3 per entry
@@ -309,6 +310,38 @@ __device__ __forceinline__ bool tri_test_cell(const float4 q0, const float4 q1, 
     return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
 }
 
+// The reference's test with nothing in front of it: the four determinants in its operation order, the three
+// quotients, its five comparisons.  For the frame walks, whose plane heads (below) have already dropped the
+// tests tri_test_cell's first stage was written for: what reaches the exact test there is a wave of which half the
+// lanes hold a triangle whose plane the ray crosses inside the current cell, most such waves hold a real hit,
+// and a stage that any lane needs is run by the wave - the staged early returns then only add their
+// comparisons and the bookkeeping of who is still in (66 of 162 vector instructions).
+__device__ __forceinline__ bool tri_test_line(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d,
+                                              float minT, float& a, float& b, float& t)
+{
+    const float e1x = q0.x, e1y = q0.y, e1z = q0.z, e2x = q0.w, e2y = q1.x, e2z = q1.y;
+    const float cx = o.x - q1.z, cy = o.y - q1.w, cz = o.z - q2.x;
+    const float p1 = q2.y, p4 = q2.z; // e1x*e2y, e1z*e2y
+    const float e2x_dy = e2x * d.y, dx_e1y = d.x * e1y, e2z_dy = e2z * d.y, dz_e1y = d.z * e1y;
+    const float D = p1 * d.z + e2x_dy * e1z + dx_e1y * e2z - p4 * d.x - e2z_dy * e1x - dz_e1y * e2x;
+    const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
+                     e2z_dy * cx - (d.z * cy) * e2x;
+    const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
+                     (cz * d.y) * e1x - dz_e1y * cx;
+    const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
+                     (cz * e1y) * e2x;
+    if (D == 0.0f) { // Matrix33.h:132-134: solve() returns (0,0,0); t = -0.0f
+        a = 0.0f;
+        b = 0.0f;
+        t = -0.0f;
+    } else {
+        float q;
+        div3_rn(da, db, dt, D, a, b, q);
+        t = -q;
+    }
+    return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
+}
+
 // The plane head of a slot, and what it decides.  With n = e1 x e2, the determinant of the reference's test is
 // D = n . dir and the numerator of t is N = n . (o - v2), t = -(N / D): where the ray crosses the triangle's
 // plane.  A walk that knows the stretch [lo, hi] of the ray inside its cell (tri_test_cell) drops four tests in
@@ -332,11 +365,11 @@ __device__ __forceinline__ void tri_head_bounds(f3 o, f3 d, float vert_l1, float
 }
 
 __device__ __forceinline__ bool tri_head_keep(const float4 hd, f3 o, f3 d, float eD, float eN, float lo_s,
-                                              float hi_s)
+                                              float hi_s, float& Dh, float& Nh)
 {
     // lo_s = lo / 1.000001, hi_s = hi * 1.000001 (the rounding of the reference's quotient)
-    const float Dh = __builtin_fmaf(hd.x, d.x, __builtin_fmaf(hd.y, d.y, hd.z * d.z));
-    const float Nh = __builtin_fmaf(hd.x, o.x, __builtin_fmaf(hd.y, o.y, __builtin_fmaf(hd.z, o.z, -hd.w)));
+    Dh = __builtin_fmaf(hd.x, d.x, __builtin_fmaf(hd.y, d.y, hd.z * d.z));
+    Nh = __builtin_fmaf(hd.x, o.x, __builtin_fmaf(hd.y, o.y, __builtin_fmaf(hd.z, o.z, -hd.w)));
     const float lowD = fabsf(Dh) - eD, upD = fabsf(Dh) + eD; // |D| / B lies in [lowD, upD]
     // nq = N sign(D) = -t |D|
     const float nq = __uint_as_float(__float_as_uint(Nh) ^ (__float_as_uint(Dh) & 0x80000000u));
@@ -346,6 +379,44 @@ __device__ __forceinline__ bool tri_head_keep(const float4 hd, f3 o, f3 d, float
     const int beyond = nq + eN < -(hi_s * upD); // t > hi
     const int before = eN - nq < lo_s * lowD;   // t < lo
     return !(sure & (behind | beyond | before));
+}
+
+// The edge record of a slot, and what it decides.  A ray that crosses the triangle's plane inside the cell (the
+// plane head lets it through) still misses the triangle three times in four, and it does so together with its
+// neighbours: of the wave trips through the exact test that any lane asks for, three in four find no hit in any
+// lane.  Where the plane is crossed decides a and b: with n = e1 x e2, ga = (e2 x n) / n.n and gb = (n x e1) / n.n,
+// a = ga . (P - v2) and b = gb . (P - v2) for a point P of the plane, and with P = o + t dir, t = -N / D:
+//   a D = (ga . o + ka) D - N (ga . dir),  ka = -ga . v2      (likewise b; all of it times the head's 1 / B)
+// - eight fused operations per coordinate from the head's D and N, no division.  The record holds (ga, ka) and
+// (gb, kb) times s = 1 / max |component of ga, gb|, and s.  Again the decision only has to be safe: the reference
+// rejects on the SIGN of its a and b, and the sign of a rounded determinant is certain once the exact one
+// exceeds 7 * 2^-24 times the sum of the absolute triple products, which is at most |c|_1 |dir|_1 max|e2_j|
+// (c = o - v2); times s / B that is at most 21 * 2^-24 * so * sd (s <= sqrt 3 |n| / |e|, B >= |n| / sqrt 3; so, sd
+// the two sums of tri_head_bounds), our own roundings add 26 * 2^-24 * so * sd: T = 2^-18 so sd covers both.
+// a + b > 1 is certain when s |D| (a + b - 1) clears 4 T plus 2^-12 (|a| + |b|) s |D| - the relative error of
+// the reference's quotients, 7 * 2^-24 |dir|_1 B / |D|, is below that for |D| / B >= 2^-8 |dir|_1, and steeper
+// crossings only are decided on this rule.  Nothing is decided unless the sign of D is certain; a degenerate
+// triangle has a zero record: never dropped.  What is kept goes on to the exact test, so hits and their a, b, t
+// stay the reference's bits.
+__device__ __forceinline__ bool tri_edges_keep(const float4 E0, const float4 E1, const float s, f3 o, f3 d, float Dh,
+                                               float Nh, float eD, float eN)
+{
+    const float Ao = __builtin_fmaf(E0.x, o.x, __builtin_fmaf(E0.y, o.y, __builtin_fmaf(E0.z, o.z, E0.w)));
+    const float Ad = __builtin_fmaf(E0.x, d.x, __builtin_fmaf(E0.y, d.y, E0.z * d.z));
+    const float Bo = __builtin_fmaf(E1.x, o.x, __builtin_fmaf(E1.y, o.y, __builtin_fmaf(E1.z, o.z, E1.w)));
+    const float Bd = __builtin_fmaf(E1.x, d.x, __builtin_fmaf(E1.y, d.y, E1.z * d.z));
+    const float Xa = __builtin_fmaf(Ao, Dh, -(Nh * Ad)), Xb = __builtin_fmaf(Bo, Dh, -(Nh * Bd));
+    const unsigned sg = __float_as_uint(Dh) & 0x80000000u;
+    const float    xa = __uint_as_float(__float_as_uint(Xa) ^ sg), xb = __uint_as_float(__float_as_uint(Xb) ^ sg);
+    const float    T = (eD * 2097152.0f) * eN; // 2^-18 so sd (eD = 2^-20 sd, eN = 2^-19 so)
+    const float    aD = fabsf(Dh), lowD = aD - eD;
+    const int      sure = lowD > 0.0f;
+    const int      ra = xa < -T, rb = xb < -T;
+    const float    xs = __builtin_fmaf(-s, aD, xa + xb); // s |D| (a + b - 1)
+    const float    thr = __builtin_fmaf(fabsf(xa) + fabsf(xb), 2.44140625e-4f, 4.0f * T);
+    const int      steep = lowD >= eD * 4096.0f;
+    const int      rc = steep & (xs > thr);
+    return !(sure & (ra | rb | rc));
 }
 
 #define RT_TRAV_EPS 1e-5f

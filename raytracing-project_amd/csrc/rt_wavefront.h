@@ -71,6 +71,9 @@ struct WfShared {
     int n_closest, n_shadow; // rays traced (statistics; counted per wave here, not in a register per lane)
     int region;   // k_wf_pipeline: the region the block works on
     int batch[2]; // k_wf_pipeline: next 64 rays of the stage to hand to a wave (stages alternate between the two)
+#ifdef WF_SECT
+    unsigned long long sect[10]; // cycles per part of a stage, summed over the block's waves (flushed when the block ends)
+#endif
 };
 
 // One level's rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
@@ -165,10 +168,12 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int pa
 // block, and with it the number of resident waves, does not grow with the depth of the tree.
 // (Until the node index took 32 bits the entry was a 16-bit node beside a float in two arrays: two
 // LDS instructions and two addresses per push, and no scene beyond 65535 nodes on this path.)
+typedef unsigned __attribute__((ext_vector_type(2))) wf_u2; // (a plain vector type: assignable across address spaces)
+typedef __attribute__((address_space(3))) wf_u2* WfLdsEntries; // typed as LDS: ds_read_b64 / ds_write_b64, not flat
 struct WfStack {
-    uint2* lds;
-    uint2* spill;
-    int    cap;
+    WfLdsEntries lds;
+    uint2*       spill;
+    int          cap;
 };
 
 // LDS layout per block: uint2 entry[cap][WF_BLOCK]
@@ -178,27 +183,36 @@ __device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_me
 {
     WfStack k;
     k.cap = S.stk_cap;
-    k.lds = (uint2*)s_mem + threadIdx.x;
+    k.lds = (WfLdsEntries)s_mem + threadIdx.x;
     const size_t deep = (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK;
     k.spill = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
     return k;
 }
 
+// (The two branches address different address spaces on purpose: written against one generic pointer the
+// compiler joins them into flat stores and loads, which go through the LDS and the vector-memory path both.)
 __device__ __forceinline__ void wf_stk_put(const WfStack& k, int e, int node, float t)
 {
     const uint2 v = make_uint2((unsigned)node, __float_as_uint(t));
-    if (e < k.cap) k.lds[e * WF_BLOCK] = v;
+    if (e < k.cap) k.lds[e * WF_BLOCK] = wf_u2{v.x, v.y};
     else k.spill[(size_t)(e - k.cap) * WF_BLOCK] = v;
 }
 
-__device__ __forceinline__ uint2 wf_stk_get(const WfStack& k, int e)
+// The entry on top of a stack of sp >= 1 entries and the entry t of the one below it (3.4e38, just short of FLT_MAX, if there is none):
+// what a pop needs, fetched together - the popped subtree ends where the entry below begins.
+__device__ __forceinline__ void wf_stk_top2(const WfStack& k, int sp, uint2& top, float& t_below)
 {
-    return e < k.cap ? k.lds[e * WF_BLOCK] : k.spill[(size_t)(e - k.cap) * WF_BLOCK];
-}
-
-__device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
-{
-    return __uint_as_float(e < k.cap ? k.lds[e * WF_BLOCK].y : k.spill[(size_t)(e - k.cap) * WF_BLOCK].y);
+    if (sp <= k.cap) { // both in LDS: one instruction (ds_read2st64_b64)
+        const int          lo = sp >= 2 ? sp - 2 : 0; // with a single entry the pair read is entries 0 and 1
+        const WfLdsEntries p = k.lds + lo * WF_BLOCK;
+        const wf_u2        a = p[0], b = p[WF_BLOCK];
+        top = sp >= 2 ? make_uint2(b.x, b.y) : make_uint2(a.x, a.y);
+        t_below = sp >= 2 ? __uint_as_float(a.y) : 3.4e38f;
+    } else {
+        const int e = sp - 1;
+        top = k.spill[(size_t)(e - k.cap) * WF_BLOCK];
+        t_below = __uint_as_float(e - 1 < k.cap ? ((wf_u2)k.lds[(e - 1) * WF_BLOCK]).y : k.spill[(size_t)(e - 1 - k.cap) * WF_BLOCK].y); // (cap >= 1: e >= 1)
+    }
 }
 
 // Closest-hit (ANY = false) or any-hit (ANY = true) walk of one ray over the compact node
@@ -235,6 +249,20 @@ __device__ __forceinline__ float wf_stk_t(const WfStack& k, int e)
 __device__ unsigned long long g_diag[16]; // [4..7]: shadow rays traced / occluded, their triangle tests / node steps;
                                          // [8] wave trips of the triangle loop in which a lane passes the plane head, [9] such lanes,
                                          // [10] leaf visits by waves (trips of the outer loop), [11] lanes entering a leaf with triangles
+#endif
+#ifdef WF_SECT
+// Diagnostic builds only (-DWF_SECT): core-clock cycles the waves of the counted launch spend in each part of a
+// stage, summed over waves: [0] taking a batch, [1] forming or fetching the ray, [2] closest-hit walk, [3] any-hit
+// walk of a pixel-centre ray, [4] shading, [5] fetching a shadow ray, [6] its walk, [7] reporting its answer,
+// [8] waiting at the stage's barrier, [9] pixel resolve and taking the next region.
+__device__ unsigned long long g_sect[16];
+#define WF_SC_BEGIN unsigned long long sc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter()
+#define WF_SC(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); sc_[i] += n_ - tp_; tp_ = n_; } while (0)
+#define WF_SC_END do { if (COUNT && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 10; ++i_) if (sc_[i_]) atomicAdd(&sh->sect[i_], sc_[i_]); } while (0)
+#else
+#define WF_SC_BEGIN do { } while (0)
+#define WF_SC(i) do { } while (0)
+#define WF_SC_END do { } while (0)
 #endif
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
@@ -298,9 +326,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const int     slot = first + i;
             const float4* rec = S.tris + (size_t)RT_SLOT_F4 * slot;
             float4        hd = rec[0];
-#ifdef WF_HEAD_SPECULATIVE // the rest of the slot asked for with the head and waited for only by survivors: 8.08 vs 7.67 ms
-            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
-#endif
+            // (the rest of the slot asked for with the head and waited for only by survivors: 8.08 vs 7.67 ms)
             if (COUNT) ++n_tests;
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
@@ -308,19 +334,45 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             // (the head as one 16-byte load, complete here: the compiler would otherwise fetch its last word
             // later, behind a wait for the whole slot)
             asm volatile("" ::"v"(hd.x), "v"(hd.y), "v"(hd.z), "v"(hd.w));
+            float Dh, Nh;
+            const bool keep = tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s, Dh, Nh);
 #ifdef WF_DIAG
             if (COUNT) {
-                const bool k_ = tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s);
-                const unsigned long long a_ = __ballot(1), m_ = __ballot(k_);
+                const unsigned long long a_ = __ballot(1), m_ = __ballot(keep);
                 if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[8], 1ull), atomicAdd(&g_diag[9], (unsigned long long)__popcll(m_));
             }
 #endif
-            if (!tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s)) continue;
-#ifndef WF_HEAD_SPECULATIVE
-            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
+            if (!keep) continue;
+#ifndef WF_NO_EDGES
+            {
+                const float4* er = S.edges + (size_t)3 * slot;
+                const float4  E0 = er[0], E1 = er[1];
+                const float   es = er[2].x;
+                const bool    keep2 = tri_edges_keep(E0, E1, es, o, d, Dh, Nh, eD, eN);
+#ifdef WF_DIAG
+                if (COUNT) {
+                    const unsigned long long a_ = __ballot(1), m_ = __ballot(keep2);
+                    if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[14], 1ull), atomicAdd(&g_diag[15], (unsigned long long)__popcll(m_));
+                }
 #endif
+                if (!keep2) continue;
+            }
+#endif
+            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
             float a, b, t;
+#ifdef WF_DIAG
+            if (COUNT) {
+                float a_, b_, t_;
+                const bool ok_ = tri_test_line(q0, q1, q2, o, d, minT, a_, b_, t_);
+                const unsigned long long m_ = __ballot(1), h_ = __ballot(ok_);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1 && h_) atomicAdd(&g_diag[12], 1ull), atomicAdd(&g_diag[13], (unsigned long long)__popcll(h_));
+            }
+#endif
+#ifdef WF_TRI_STAGED
             if (tri_test_cell(q0, q1, q2, o, d, minT, lo, ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f), a, b, t)) {
+#else
+            if (tri_test_line(q0, q1, q2, o, d, minT, a, b, t)) {
+#endif
                 if (ANY) return true;
                 const int orig = __float_as_int(q2.w);
                 bool      take = t != minT || best_orig < 0;
@@ -335,13 +387,15 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         if (!ANY && minT < tmax_e * 0.998f) break;
         bool found = false;
         while (sp > 0) {
+            uint2 top;
+            float t_below;
+            wf_stk_top2(stk, sp, top, t_below);
             --sp;
-            const uint2 top = wf_stk_get(stk, sp);
             const float et = __uint_as_float(top.y);
             if (!ANY && et * (1.0f - RT_TRAV_EPS) > minT) continue;
             node = (int)top.x;
             tmin_e = et * (1.0f - RT_TRAV_EPS);
-            tmax_e = sp > 0 ? wf_stk_t(stk, sp - 1) * (1.0f + RT_TRAV_EPS) : RT_FLT_MAX;
+            tmax_e = t_below * (1.0f + RT_TRAV_EPS);
             found = true;
             break;
         }
@@ -1117,10 +1171,12 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     const size_t sq_in = in0 * P.n_lights * (SOFT ? B.ns : 1);
     // A wave takes the next 64 rays when it is through with the last: the walks of a mirror corridor are
     // ten times as long as those next to them, and with a fixed share per wave three waves wait for the fourth.
+    WF_SC_BEGIN;
     for (;;) {
         int i0 = 0;
         if (lane == 0) i0 = atomicAdd(&sh->batch[par], 1) * 64;
         i0 = __builtin_amdgcn_readfirstlane(i0);
+        WF_SC(0);
         if (i0 >= total) break;
         int idx = i0 + lane;
         asm volatile("" : "+v"(idx)); // keeps per-lane addresses from being formed (and spilled) ahead of the loop
@@ -1165,11 +1221,13 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             HitRec   h;
             h.slot = -1, h.a = 0.0f, h.b = 0.0f, h.t = RT_FLT_MAX;
             bool got = false;
+            WF_SC(1);
             // The pixel-centre ray only decides whether the pixel's samples are traced (main.cpp:439-445); unless
             // the caller wants its triangle, any hit answers that, and the walk ends at the first one.
             if (kind == WF_ST_CENTRE && !A->tri) {
                 if (valid) got = wf_traverse<true, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
             } else if (valid) got = wf_traverse<false, COUNT>(S, stk, o, dir, h, st.n_tests, st.n_nodes);
+            WF_SC(kind == WF_ST_CENTRE ? 3 : 2);
             int j = idx;
             asm volatile("" : "+v"(j)); // what follows is computed after the walk, not carried through it
             if (kind == WF_ST_CENTRE) { // misses are final pixels, hits queue their samples
@@ -1191,6 +1249,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                 wf_shade_ray<SOFT>(S, P, B, out, g, valid, j, o, dir, w, ni, meta, got, h.slot, h.a, h.b, h.t,
                                    st.n_shaded, st.n_child);
             }
+            WF_SC(4);
         } else if (idx < total) {
             const float4 ow = B.sh_org[sq_in + (idx - seg_c)];
             const f3     o = mk3(ow.x, ow.y, ow.z);
@@ -1205,7 +1264,9 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
 #ifdef WF_DIAG
             const unsigned t0_ = st.n_tests, n0_ = st.n_nodes;
 #endif
+            WF_SC(5);
             const bool got = wf_traverse<true, COUNT>(S, stk, o, l - o, h, st.n_tests, st.n_nodes);
+            WF_SC(6);
 #ifdef WF_DIAG
             if (COUNT) {
                 atomicAdd(&g_diag[4], 1ull), atomicAdd(&g_diag[5], got ? 1ull : 0ull);
@@ -1214,8 +1275,12 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
 #endif
             wf_shadow_done<SOFT>(P, B, in0 + (__float_as_int(ow.w) & 0xffffff),
                                  g.acc, g.acc0, li, got);
+            WF_SC(7);
         }
     }
+    __syncthreads();
+    WF_SC(8);
+    WF_SC_END;
 }
 
 template <bool COUNT, bool SOFT>
@@ -1230,6 +1295,9 @@ k_wf_pipeline(WfLaunch)
     // hundred KB (11.5 -> 10.6 ms per 4K frame against a set per region), and the workspace does
     // not grow with the frame.
     const int qr = blockIdx.x;
+#ifdef WF_SECT
+    if (threadIdx.x < 10) sh.sect[threadIdx.x] = 0;
+#endif
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1251,8 +1319,7 @@ k_wf_pipeline(WfLaunch)
             const int level = stage > 1 ? stage - 1 : 0; // stage 6 = level 5: only the shadow rays of level 4
             if (stage > 1 && __builtin_amdgcn_readfirstlane(sh.child[level % 3] | sh.shd[(level + 2) % 3]) == 0) break;
             wf_stage<COUNT, SOFT>(stage == 0 ? WF_ST_CENTRE : (stage == 1 ? WF_ST_CAMERA : WF_ST_LEVEL), level, r, qr,
-                                  &sh, s_mem, st);
-            __syncthreads();
+                                  &sh, s_mem, st); // ends with the stage's barrier
             WF_TL(1 + stage);
         }
         WF_TL(13);
@@ -1281,6 +1348,10 @@ k_wf_pipeline(WfLaunch)
         }
         WF_TL(14);
     }
+#ifdef WF_SECT
+    __syncthreads();
+    if (COUNT && threadIdx.x < 10) atomicAdd(&g_sect[threadIdx.x], sh.sect[threadIdx.x]);
+#endif
     DCounters* ctr = wf_args()->ctr;
     for (int s = 32; s > 0; s >>= 1) {
         st.n_tests += __shfl_down(st.n_tests, s);
