@@ -505,6 +505,14 @@ struct RtScene {
     int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
     int        wf_cus = 0;                              // compute units of the device
+    // the hand-out order of the single launch's regions (k_wf_order): the durations the last launch left, the
+    // order made from them, the shape of the launch they belong to (0: none yet), and how many regions fit
+    unsigned*  wf_cost = nullptr;
+    int*       wf_order = nullptr;
+    uint64_t   wf_order_key = 0;
+    size_t     wf_order_cap = 0;
+    bool       wf_feedback = true;                      // RT_WF_FEEDBACK=0: regions by index, always
+    float      wf_hot = 0.3f;                           // a region that takes this share of what is left of the launch when its turn comes, or more, goes first (RT_WF_HOT)
     size_t     wf_single_lds = 0;                       // last LDS size the single launch was sized for, and
     int        wf_single_grid = 0;                      // the blocks that stay resident with it
     void*      d_stk_spill = nullptr; // deep traversal stack entries of the wavefront kernels
@@ -581,7 +589,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges, s->wf_cost, s->wf_order};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
@@ -1189,6 +1197,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         s->cfg.kd_stats = getenv("RT_KD_STATS") != nullptr;
         s->cfg.pipes = std::max(1, num("RT_WF_PIPES")), s->cfg.region = num("RT_WF_REGION");
         s->cfg.stack_lds = num("RT_WF_STACK_LDS"), s->cfg.budget_mb = num("RT_WF_BUDGET_MB");
+        const char* fb = getenv("RT_WF_FEEDBACK");
+        s->wf_feedback = !(fb && fb[0] == '0');
+        if (const char* h = getenv("RT_WF_HOT")) s->wf_hot = (float)atof(h);
     }
     int rc;
     if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) || (rc = upload(&s->d_edges, edges, &s->bytes)) ||
@@ -1748,8 +1759,36 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         if (P.msaa > 1 || !d_tri) C[0].s_tri = nullptr; // nobody reads the samples' triangles then
         A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
         A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.ctr = s->d_ctr;
+        // Regions in the order of the durations the last launch of this shape measured, longest first
+        // (k_wf_order); by index the first time, after a change of shape, and for launches of a few regions.
+        A.order = nullptr, A.cost = nullptr;
+        const bool feedback = s->wf_feedback && A.n_regions > pl.G;
+        if (feedback) {
+            if ((size_t)A.n_regions > s->wf_order_cap) {
+                if (s->wf_cost) (void)hipFree(s->wf_cost);
+                if (s->wf_order) (void)hipFree(s->wf_order);
+                s->wf_cost = nullptr, s->wf_order = nullptr, s->wf_order_cap = 0, s->wf_order_key = 0;
+                HIP_TRY(hipMalloc((void**)&s->wf_cost, sizeof(unsigned) * (size_t)A.n_regions));
+                HIP_TRY(hipMalloc((void**)&s->wf_order, sizeof(int) * (size_t)A.n_regions));
+                s->wf_order_cap = (size_t)A.n_regions;
+            }
+            // what the durations belong to: the frame, its sampling, this rank's part of it, the region size
+            uint64_t key = 1469598103934665603ull;
+            for (uint64_t v : {(uint64_t)P.W, (uint64_t)P.H, (uint64_t)P.msaa, (uint64_t)P.tile_w, (uint64_t)P.tile_h,
+                               (uint64_t)P.rank, (uint64_t)P.world, (uint64_t)P.span, (uint64_t)n_slots, (uint64_t)S,
+                               (uint64_t)P.soft_n})
+                key = (key ^ v) * 1099511628211ull;
+            if (key == 0) key = 1;
+            A.cost = s->wf_cost;
+            if (s->wf_order_key == key) A.order = s->wf_order;
+            s->wf_order_key = key;
+        }
         hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), lds_single, st, A); // pl.G <= resident blocks
         HIP_TRY(hipGetLastError());
+        if (feedback) {
+            hipLaunchKernelGGL(k_wf_order, dim3(1), dim3(1024), 0, st, (const unsigned*)s->wf_cost, A.n_regions, s->wf_hot, (int)pl.G, s->wf_order);
+            HIP_TRY(hipGetLastError());
+        }
     }
     for (long long round0 = 0; !single && round0 < n_slots; round0 += pl.chunk_slots * n_pipes) {
         long long slot0[WF_MAX_PIPES];

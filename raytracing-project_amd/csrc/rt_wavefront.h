@@ -1096,6 +1096,8 @@ struct WfLaunch {
     float*     depth;
     int*       tri;
     DCounters* ctr;
+    const int* order; // regions in the order they are handed out (null: by index), see k_wf_order
+    unsigned*  cost;  // per region: how long it took this time (null: not recorded)
 };
 typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
 
@@ -1165,7 +1167,12 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     const int par = kind == WF_ST_CENTRE ? 1 : (level & 1); // centre 1, camera 0, level l: l & 1
     if (threadIdx.x == 0) sh->batch[par ^ 1] = 0;             // the stage after this one counts from 0
     const WfRays in = wf_ld(A->B.rays[level & 1]), out = wf_ld(A->B.rays[(level + 1) & 1]);
-    const int    seg_c = (n_first + 63) & ~63;
+#ifdef WF_BATCH_ALWAYS
+    const int bw = WF_BATCH_ALWAYS;
+#else
+    const int bw = 64;
+#endif
+    const int    seg_c = (n_first + bw - 1) & ~(bw - 1);
     const int    total = seg_c + n_sh;
     const int    lane = threadIdx.x & 63;
     const size_t sq_in = in0 * P.n_lights * (SOFT ? B.ns : 1);
@@ -1174,7 +1181,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     WF_SC_BEGIN;
     for (;;) {
         int i0 = 0;
-        if (lane == 0) i0 = atomicAdd(&sh->batch[par], 1) * 64;
+        if (lane == 0) i0 = atomicAdd(&sh->batch[par], 1) * bw;
         i0 = __builtin_amdgcn_readfirstlane(i0);
         WF_SC(0);
         if (i0 >= total) break;
@@ -1184,7 +1191,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             // Before the walk only the ray itself is formed; whatever else the shading needs (weight,
             // prev_Ni, sample, queue addresses) is fetched or derived again afterwards from the
             // lane's index, so that it does not sit in registers - or in scratch - during the walk.
-            bool valid = idx < n_first;
+            bool valid = lane < bw && idx < n_first;
             f3   o = mk3(0, 0, 0), dst = mk3(0, 0, 0);
             int  xy = 0;
             if (kind == WF_ST_LEVEL) {
@@ -1250,7 +1257,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                                    st.n_shaded, st.n_child);
             }
             WF_SC(4);
-        } else if (idx < total) {
+        } else if (lane < bw && idx < total) {
             const float4 ow = B.sh_org[sq_in + (idx - seg_c)];
             const f3     o = mk3(ow.x, ow.y, ow.z);
             const int    li = (int)((unsigned)__float_as_int(ow.w) >> 24);
@@ -1260,7 +1267,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                 l = mk3(dd.x, dd.y, dd.z);
             }
             HitRec h;
-            if (idx == i0) atomicAdd(&sh->n_shadow, min(64, total - i0));
+            if (idx == i0) atomicAdd(&sh->n_shadow, min(bw, total - i0));
 #ifdef WF_DIAG
             const unsigned t0_ = st.n_tests, n0_ = st.n_nodes;
 #endif
@@ -1283,6 +1290,93 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     WF_SC_END;
 }
 
+// The order in which the next frame's regions are handed out: the longest first.  The launch ends when its
+// last region does, and a region that mirrors keep busy for five levels takes ten to twenty times the median
+// (1 ms against 0.1 ms at 1080p) however empty the GPU around it is; handed out by index such a region starts
+// whenever its turn comes, and the blocks that are through wait for it (a quarter of the launch for a 1080p
+// frame, a third for an eighth of a 4K frame).  Nothing cheap predicts a region's cost before it runs - but
+// the frame before this one measured it: a renderer is asked for the same or a neighbouring view again and
+// again, and the cost of a patch of screen changes slowly with the view.  So every region leaves its duration
+// behind (WfLaunch::cost), and this kernel sorts the regions by it, longest first, for the next launch of the
+// same shape: bins of a quarter octave, stable counting sort, one block.  It is a hint and nothing else: every
+// region is rendered whatever the order, the sums are order-free, the frame is the same bit for bit.
+#define WF_ORDER_BINS 128
+__device__ __forceinline__ int wf_order_bin(unsigned c) // bin 0 holds the longest: quarter octaves of the cost, reversed
+{
+    if (c == 0) return WF_ORDER_BINS - 1;
+    const int e = 31 - __clz((int)c);
+    const int q = e >= 2 ? (int)((c >> (e - 2)) & 3u) : 0;
+    return WF_ORDER_BINS - 1 - (4 * e + q);
+}
+
+// Stable: regions of one bin keep their index order, so neighbouring regions - which walk the same part of the
+// tree - are still handed out one after the other (in whatever order the atomics came, a frame of equally
+// expensive regions took 3 % longer than by index).  Each of the 16 waves owns a contiguous run of regions.
+__global__ void __launch_bounds__(1024) k_wf_order(const unsigned* __restrict__ cost, int n, float hot, int blocks, int* __restrict__ order)
+{
+    __shared__ int                s_at[16][WF_ORDER_BINS]; // first the count of a wave's regions per bin, then where its next one goes
+    __shared__ unsigned long long s_sum;
+    const int                     t = threadIdx.x, w = t >> 6, lane = t & 63;
+    for (int i = t; i < 16 * WF_ORDER_BINS; i += 1024) (&s_at[0][0])[i] = 0;
+    if (t == 0) s_sum = 0;
+    __syncthreads();
+    const int per = ((n + 15) / 16 + 63) & ~63; // regions per wave, whole rounds of 64
+    const int lo = min(w * per, n), hi = min(lo + per, n);
+    {
+        unsigned long long mine = 0;
+        for (int i = lo + lane; i < hi; i += 64) mine += cost[i];
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+        if (lane == 0) atomicAdd(&s_sum, mine);
+    }
+    __syncthreads();
+    // Only the regions a launch by index would end up waiting for are moved to the front: region i of n starts
+    // when about i / n of the launch is over (the launch takes the sum of the durations over the blocks), and
+    // matters if it would still be running near the end - if it takes `hot` times what is left by then, or
+    // longer.  Everything else stays in index order behind them.  (Sorting all regions by duration puts the
+    // expensive ones on the GPU at the same time, where they take longer than mixed with cheap ones: lego
+    // 4K 3.75 ms by index, 4.0 ms sorted; final 4K: the tail gone and nearly as much lost before it.)
+    const float left_per_region = (float)((double)s_sum / (double)max(blocks, 1)) * hot / (float)max(n, 1);
+    auto bin = [&](unsigned c, int i) {
+        return (float)c >= left_per_region * (float)(n - i) ? min(wf_order_bin(c), WF_ORDER_BINS - 2) : WF_ORDER_BINS - 1;
+    };
+    for (int i = lo + lane; i < hi; i += 64) atomicAdd(&s_at[w][bin(cost[i], i)], 1);
+    __syncthreads();
+    __shared__ int s_total[WF_ORDER_BINS];
+    if (t < WF_ORDER_BINS) { // within bin t: where each wave's regions start
+        int run = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int c = s_at[k][t];
+            s_at[k][t] = run;
+            run += c;
+        }
+        s_total[t] = run;
+    }
+    __syncthreads();
+    if (t < WF_ORDER_BINS) { // plus all regions of the bins before it
+        int before = 0;
+        for (int b = 0; b < t; ++b) before += s_total[b];
+        for (int k = 0; k < 16; ++k) s_at[k][t] += before;
+    }
+    __syncthreads();
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int  i = i0 + lane;
+        const bool valid = i < hi;
+        const int  b = valid ? bin(cost[i], i) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) { // the lanes of one bin take consecutive places, in lane order
+            const int                leader = __ffsll((long long)todo) - 1;
+            const int                lb = __shfl(b, leader);
+            const unsigned long long m = __ballot(valid && b == lb);
+            const int                base = s_at[w][lb];
+            if (valid && b == lb) order[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) s_at[w][lb] = base + __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~m;
+        }
+    }
+}
+
 template <bool COUNT, bool SOFT>
 __global__ void __launch_bounds__(WF_BLOCK, WF_PIPE_WAVES)
 k_wf_pipeline(WfLaunch)
@@ -1301,7 +1395,9 @@ k_wf_pipeline(WfLaunch)
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            sh.region = atomicAdd(&wf_args()->B.ctr->head_region, 1);
+            const int        next = atomicAdd(&wf_args()->B.ctr->head_region, 1);
+            const WfLaunchC  A0 = wf_args();
+            sh.region = (A0->order && next < A0->n_regions) ? A0->order[next] : next;
             sh.child[1] = 0, sh.shd[0] = 0, sh.n_hit = 0, sh.n_cam = 0; // what the camera stage appends to
             sh.batch[0] = 0, sh.batch[1] = 0;
             sh.n_closest = 0, sh.n_shadow = 0;
@@ -1309,6 +1405,7 @@ k_wf_pipeline(WfLaunch)
         __syncthreads();
         const int r = __builtin_amdgcn_readfirstlane(sh.region);
         if (r >= wf_args()->n_regions) break;
+        const unsigned long long t_region = wf_args()->cost ? wall_clock64() : 0ull;
         WF_TL(0);
 #ifdef WF_TIMELINE
         if (threadIdx.x == 0 && r < WF_TL_REGIONS) g_timeline[(size_t)r * 16 + 15] = blockIdx.x;
@@ -1347,6 +1444,8 @@ k_wf_pipeline(WfLaunch)
             }
         }
         WF_TL(14);
+        if (threadIdx.x == 0 && wf_args()->cost) // (100 MHz ticks; a region takes 20 us to a few ms)
+            wf_args()->cost[r] = (unsigned)min(wall_clock64() - t_region, 0xffffffffull) + 1u;
     }
 #ifdef WF_SECT
     __syncthreads();

@@ -516,6 +516,32 @@ def test_render_paths_agree(P, oracle, monkeypatch):
     assert a[3].rays_closest == c[3].rays_closest
 
 
+def test_region_order_from_the_last_frame_changes_nothing(P, monkeypatch):
+    """From the second frame of a shape on, the single launch hands its regions out in the order of the
+    durations the frame before measured (k_wf_order).  That is a hint about when a region runs, never about
+    what it renders: frames 2 and 3 of a scene equal its first frame and the frame of a scene that never
+    reorders (RT_WF_FEEDBACK=0), bit for bit, also across a change of shape and for one rank's share of a deal."""
+    monkeypatch.delenv("RT_WF_FEEDBACK", raising=False)
+    hs, gs, m, lights = _host_gpu(P, "refractionballs")
+    monkeypatch.setenv("RT_WF_FEEDBACK", "0")
+    plain = hs.to_gpu(0)
+    monkeypatch.delenv("RT_WF_FEEDBACK", raising=False)
+    for W, H, msaa, world in ((800, 600, 1, 1), (512, 384, 4, 1), (800, 600, 1, 1), (800, 608, 1, 2)):
+        corners = P.host.camera_corners(m, W, H)
+        p = P.capi.default_params(W, H, msaa)
+        if world > 1:
+            p.tile_w = p.tile_h = 32
+            p.world, p.rank = world, 1
+        want = plain.render(corners, lights, p)
+        assert want[3].rays_closest > 0
+        for it in range(3):
+            got = gs.render(corners, lights, p)
+            assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (W, H, msaa, it)
+            assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+            assert np.array_equal(got[2], want[2])
+            assert got[3].rays_closest == want[3].rays_closest and got[3].rays_shadow == want[3].rays_shadow
+
+
 def test_chunked_frame_and_many_lights(P, monkeypatch):
     """A frame too large for its workspace is rendered in chunks of regions (here forced with
     a 2 MB budget), in both launch structures; 40 lights stretch the per-light queues.  All
