@@ -31,7 +31,9 @@ the line also carries a record per other BASELINE config ("configs"), the wall
 time of the drop-in 'r' path ("r_path_ms"), an eighth of the frame alone and with two frames in flight
 ("frame_parts_in_flight": what a rank of eight GPUs would render) and the CPU baseline.  For every N the
 K steps are timed twice: with one frame in flight (the line's value and ms_per_step: the time of a
-frame) and with two ("two_frames_in_flight": the throughput of consecutive frames).
+frame) and with two ("two_frames_in_flight": the throughput of consecutive frames), and a third time with
+the regions of every launch handed out by index instead of by the durations the frame before measured
+("regions_by_index": the first frame of a view).
 """
 import argparse
 import importlib
@@ -203,10 +205,22 @@ def config_record(pkg, name, w, h, msaa, fc, dev_index, frames=5):
     kt = gs.collect_timing()
     gs.set_timing(False)
     ms = kt.frame_ms / max(kt.frames, 1)
+    # the same launches with the regions handed out by index (what the first frame of a view gets)
+    gs.set_region_order(False)
+    gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0, False)
+    torch.cuda.synchronize()
+    gs.set_timing(True)
+    for _ in range(frames):
+        gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0, False)
+    torch.cuda.synchronize()
+    kt0 = gs.collect_timing()
+    gs.set_timing(False)
+    gs.set_region_order(True)
     rays = st.rays_closest + st.rays_shadow
     key = f"{name}_{w}x{h}_msaa{msaa}"
     info = gs.info()
-    rec = {"ms_per_frame": round(ms, 3), "mrays_s": round(rays / ms / 1e3, 1), "rays_per_frame": int(rays),
+    rec = {"ms_per_frame": round(ms, 3), "ms_per_frame_regions_by_index": round(kt0.frame_ms / max(kt0.frames, 1), 3),
+           "mrays_s": round(rays / ms / 1e3, 1), "rays_per_frame": int(rays),
            "lights": len(lights), "launches_timed": kt.frames,
            "scene_create_ms": round(info["create_ms"], 2), "tree_steps_ms": round(info["tree_ms"], 2),
            "device_nodes": info["n_nodes"], "render_path": info["render_path"]}
@@ -516,7 +530,7 @@ def main():
             "torch.distributed.gather (rt_gather_tiles_rccl rebuilt a different frame)"
 
     flight_probe = None
-    if True:
+    if not args.no_extras:
         def part_ms(which, n=12):
             for rep_ in range(2):                       # the first pass warms up
                 torch.cuda.synchronize()
@@ -533,6 +547,9 @@ def main():
         flight_probe = {"render_alone_ms": round(alone, 3),
                         "with_partner_ms": {str(k): round(v, 3) for k, v in pairs.items()}, "partner": best}
         slots = [slots[0], slots[best]]                 # the others' buffers are released with them
+        torch.cuda.empty_cache()
+    else:
+        slots = slots[:2]
         torch.cuda.empty_cache()
 
     # one counted frame: rays this rank traces per frame (deterministic)
@@ -580,11 +597,33 @@ def main():
 
     elapsed, kt = timed_loop(n_flight)
     other_flight = 2 if n_flight == 1 else 1
-    elapsed_other, kt_other = timed_loop(other_flight)
+    if args.no_extras:      # profiling runs: the timed loop alone, so that the launches a profiler sees are its launches
+        elapsed_other, kt_other = elapsed, kt
+    else:
+        elapsed_other, kt_other = timed_loop(other_flight)
     flight["n"] = n_flight
+    # The library starts the regions a launch would otherwise wait for first, from the durations the frame
+    # before measured (rt_scene_set_region_order).  The timed loop above runs that way - it is what a caller
+    # gets from the second frame of a view on.  The same K steps again with the regions by index: what the
+    # first frame of a view costs.
+    by_index = None
+    if not args.no_extras:
+        for sl in slots:
+            sl["gs"].set_region_order(False)
+        el_i, kt_i = timed_loop(n_flight)
+        for sl in slots:
+            sl["gs"].set_region_order(True)
+        frame(0)
+        frame(1)
+        torch.cuda.synchronize()
+        by_index = {"ms_per_step": round(el_i / args.steps * 1e3, 3),
+                    "k_wf_pipeline_ms": round(kt_i.frame_ms / max(kt_i.frames, 1), 3),
+                    "what": "the same K steps with every launch handing its regions out by index (no durations from a "
+                            "frame before): the first frame of a view; the line's value and ms_per_step are frames "
+                            "that follow a frame of the same view"}
     # the second slot holds a whole frame of its own once a loop has given it one (bit patterns: the blurred
     # plane holds the reference's NaN pixel)
-    slot1_used = args.steps >= 2 or args.warmup >= 2
+    slot1_used = (not args.no_extras or n_flight > 1) and (args.steps >= 2 or args.warmup >= 2)
     two_equal_one = True
     if rank == 0 and slot1_used:
         two_equal_one = all(bool(torch.equal(slots[0][k_].view(torch.int32), slots[1][k_].view(torch.int32)))
@@ -634,7 +673,7 @@ def main():
             # a line from one GPU says nothing about scaling; no multi-GPU node has run this bench yet
             "scaling_measured": world > 1,
             "frames_in_flight": n_flight,
-            ("two_frames_in_flight" if other_flight == 2 else "one_frame_in_flight"): {
+            ("two_frames_in_flight" if other_flight == 2 else "one_frame_in_flight"): None if args.no_extras else {
                 "ms_per_step": round(elapsed_other / args.steps * 1e3, 3),
                 "value": round(rays_per_frame * args.steps / elapsed_other / 1e6, 2),
                 "k_wf_pipeline_ms": round(kt_other.frame_ms / max(kt_other.frames, 1), 3),
@@ -643,6 +682,7 @@ def main():
                         % (other_flight, "s" if other_flight > 1 else "",
                            "throughput of consecutive frames, the launch of frame i + 1 fills the GPU as the last "
                            "regions of frame i run out" if other_flight == 2 else "the time of one frame", n_flight)},
+            "regions_by_index": by_index,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "data": "scenes/final.obj + scenes/cameras/final.sav (the reference's own scene; no "
                     "published camera exists, this one is fixed in the repo)",

@@ -317,6 +317,16 @@ int rt_calibrate_deal(RtScene *scene, void *comm, int32_t rank, int32_t n_ranks,
                       const float *lights, int32_t n_lights, const RtParams *params,
                       int32_t *first_rank_shares);
 
+/* The order in which a frame's regions (the units of 64 to 256 pixels a block of the render launch takes)
+ * are handed out.  The reference's threads take rows top to bottom and steal from each other when they run
+ * dry (main.cpp:410-429); here a launch ends when its last region does, and a region that mirrors keep busy
+ * takes ten to twenty times the median.  from_last_frame = 1 (the default; RT_WF_FEEDBACK=0 in the
+ * environment at rt_scene_create makes 0 the default): every launch leaves the duration of each region
+ * behind, and the next launch of the same shape (frame size, sampling, this rank's tiles) starts the regions
+ * it would otherwise end up waiting for first.  A hint about when a region runs, never about what it
+ * renders: the frame is the same bit for bit.  0: always by index (what the first frame of a shape gets). */
+int rt_scene_set_region_order(RtScene *scene, int32_t from_last_frame);
+
 /* rt_render_result_planes for a frame shared by n_ranks processes, one per GPU (the C++ host's
  * replacement of the thread bands of main.cpp:329-339): this rank renders its tiles of the scene's
  * deal (above), the payloads are gathered on rank 0 (rt_gather_tiles_rccl), and rank 0 rebuilds the

@@ -85,7 +85,7 @@ EXPORTS = [
     "rt_normalize_depth", "rt_normalize_depth_device", "rt_normalize_depth_device_noalloc", "rt_dof_blur", "rt_dof_blur_device",
     "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
     "rt_rccl_unique_id", "rt_rccl_comm_create", "rt_rccl_comm_destroy", "rt_gather_tiles_rccl",
-    "rt_render_result_planes_shared", "rt_render_result_planes_rehearsal", "rt_deal_params", "rt_scene_set_deal",
+    "rt_render_result_planes_shared", "rt_render_result_planes_rehearsal", "rt_deal_params", "rt_scene_set_deal", "rt_scene_set_region_order",
     "rt_calibrate_deal",
 ]
 
@@ -146,6 +146,7 @@ def lib():
                                                     C.POINTER(P), C.POINTER(P), C.POINTER(RtStats)]
     L.rt_deal_params.argtypes = [C.POINTER(RtParams), I32, I32, I32, C.POINTER(RtParams)]
     L.rt_scene_set_deal.argtypes = [P, I32]
+    L.rt_scene_set_region_order.argtypes = [P, I32]
     L.rt_calibrate_deal.argtypes = [P, P, I32, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(I32)]
     L.rt_rccl_unique_id.argtypes = [P]
     L.rt_rccl_comm_create.argtypes = [P, I32, I32, C.c_int, C.POINTER(P)]
@@ -245,6 +246,9 @@ class Scene:
 
     def set_timing(self, enable):
         check(lib().rt_scene_set_timing(self.h, 1 if enable else 0))
+
+    def set_region_order(self, from_last_frame):
+        check(lib().rt_scene_set_region_order(self.h, 1 if from_last_frame else 0))
 
     def collect_timing(self):
         t = RtKernelTimes()

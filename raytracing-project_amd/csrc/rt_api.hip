@@ -505,10 +505,11 @@ struct RtScene {
     int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
     int        wf_cus = 0;                              // compute units of the device
-    // the hand-out order of the single launch's regions (k_wf_order): the durations the last launch left, the
+    // the hand-out order of the single launch's regions (k_wf_order_*): the durations the last launch left, the
     // order made from them, the shape of the launch they belong to (0: none yet), and how many regions fit
     unsigned*  wf_cost = nullptr;
     int*       wf_order = nullptr;
+    int*       wf_order_at = nullptr;                  // [WF_ORDER_RUNS][WF_ORDER_BINS]: scratch of the sort
     uint64_t   wf_order_key = 0;
     size_t     wf_order_cap = 0;
     bool       wf_feedback = true;                      // RT_WF_FEEDBACK=0: regions by index, always
@@ -589,7 +590,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges, s->wf_cost, s->wf_order};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges, s->wf_cost, s->wf_order, s->wf_order_at};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
@@ -934,7 +935,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         const char*  lt_env = getenv("RT_KD_LEAF");
         const char*  ci_env = getenv("RT_KD_CI");
         KdSplitParams prm;
-        prm.leaf_target = lt_env ? atoi(lt_env) : 4; // do not split leaves at or below this size
+        prm.leaf_target = lt_env ? atoi(lt_env) : 6; // do not split leaves at or below this size (4 until the plane heads made a test cheaper than a node step)
         prm.c_trav = 1.0, prm.c_isect = ci_env ? atof(ci_env) : 3.0;
         for (int a = 0; a < 3; ++a) {
             const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
@@ -1760,7 +1761,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
         A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.ctr = s->d_ctr;
         // Regions in the order of the durations the last launch of this shape measured, longest first
-        // (k_wf_order); by index the first time, after a change of shape, and for launches of a few regions.
+        // (k_wf_order_*); by index the first time, after a change of shape, and for launches of a few regions.
         A.order = nullptr, A.cost = nullptr;
         const bool feedback = s->wf_feedback && A.n_regions > pl.G;
         if (feedback) {
@@ -1770,6 +1771,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                 s->wf_cost = nullptr, s->wf_order = nullptr, s->wf_order_cap = 0, s->wf_order_key = 0;
                 HIP_TRY(hipMalloc((void**)&s->wf_cost, sizeof(unsigned) * (size_t)A.n_regions));
                 HIP_TRY(hipMalloc((void**)&s->wf_order, sizeof(int) * (size_t)A.n_regions));
+                if (!s->wf_order_at) HIP_TRY(hipMalloc((void**)&s->wf_order_at, sizeof(int) * WF_ORDER_RUNS * WF_ORDER_BINS));
                 s->wf_order_cap = (size_t)A.n_regions;
             }
             // what the durations belong to: the frame, its sampling, this rank's part of it, the region size
@@ -1786,7 +1788,12 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         hipLaunchKernelGGL(kern, dim3(pl.G), dim3(WF_BLOCK), lds_single, st, A); // pl.G <= resident blocks
         HIP_TRY(hipGetLastError());
         if (feedback) {
-            hipLaunchKernelGGL(k_wf_order, dim3(1), dim3(1024), 0, st, (const unsigned*)s->wf_cost, A.n_regions, s->wf_hot, (int)pl.G, s->wf_order);
+            const WfCounters* ctr = C[0].ctr; // (zeroed before the launch; the order kernels run before the next launch's memset)
+            hipLaunchKernelGGL(k_wf_order_count, dim3(WF_ORDER_BLOCKS), dim3(1024), 0, st, (const unsigned*)s->wf_cost,
+                               A.n_regions, s->wf_hot, (int)pl.G, ctr, s->wf_order_at);
+            hipLaunchKernelGGL(k_wf_order_offsets, dim3(1), dim3(1024), 0, st, s->wf_order_at);
+            hipLaunchKernelGGL(k_wf_order_place, dim3(WF_ORDER_BLOCKS), dim3(1024), 0, st, (const unsigned*)s->wf_cost,
+                               A.n_regions, s->wf_hot, (int)pl.G, ctr, (const int*)s->wf_order_at, s->wf_order);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -2202,6 +2209,14 @@ extern "C" int rt_deal_params(const RtParams* frame, int32_t n_ranks, int32_t fi
     out->world = first_rank_shares + RT_SHARES_PER_RANK * (n_ranks - 1);
     out->rank = rank == 0 ? 0 : first_rank_shares + RT_SHARES_PER_RANK * (rank - 1);
     out->rank_span = rank == 0 ? first_rank_shares : RT_SHARES_PER_RANK;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_region_order(RtScene* s, int32_t from_last_frame)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_region_order: null scene");
+    s->wf_feedback = from_last_frame != 0;
+    s->wf_order_key = 0; // whatever was measured before does not count from here on
     return RT_OK;
 }
 

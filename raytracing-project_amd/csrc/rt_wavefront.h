@@ -58,6 +58,7 @@ struct WfCounters {
     int head_shadow[WF_MAX_DEPTH][RT_MAX_LIGHTS_DEV];
     int head_region;                 // k_wf_pipeline: next region to hand out
     int pad;
+    unsigned long long cost_sum;     // k_wf_pipeline: sum of the durations its regions took (k_wf_order_*)
 };
 
 // Block-local state of the producer stages (LDS).  Levels rotate through three counters
@@ -1096,7 +1097,7 @@ struct WfLaunch {
     float*     depth;
     int*       tri;
     DCounters* ctr;
-    const int* order; // regions in the order they are handed out (null: by index), see k_wf_order
+    const int* order; // regions in the order they are handed out (null: by index), see k_wf_order_place
     unsigned*  cost;  // per region: how long it took this time (null: not recorded)
 };
 typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
@@ -1297,8 +1298,8 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
 // frame, a third for an eighth of a 4K frame).  Nothing cheap predicts a region's cost before it runs - but
 // the frame before this one measured it: a renderer is asked for the same or a neighbouring view again and
 // again, and the cost of a patch of screen changes slowly with the view.  So every region leaves its duration
-// behind (WfLaunch::cost), and this kernel sorts the regions by it, longest first, for the next launch of the
-// same shape: bins of a quarter octave, stable counting sort, one block.  It is a hint and nothing else: every
+// behind (WfLaunch::cost), and the kernels below sort the regions by it, longest first, for the next launch of the
+// same shape: bins of a quarter octave, stable counting sort.  It is a hint and nothing else: every
 // region is rendered whatever the order, the sums are order-free, the frame is the same bit for bit.
 #define WF_ORDER_BINS 128
 __device__ __forceinline__ int wf_order_bin(unsigned c) // bin 0 holds the longest: quarter octaves of the cost, reversed
@@ -1309,59 +1310,117 @@ __device__ __forceinline__ int wf_order_bin(unsigned c) // bin 0 holds the longe
     return WF_ORDER_BINS - 1 - (4 * e + q);
 }
 
-// Stable: regions of one bin keep their index order, so neighbouring regions - which walk the same part of the
-// tree - are still handed out one after the other (in whatever order the atomics came, a frame of equally
-// expensive regions took 3 % longer than by index).  Each of the 16 waves owns a contiguous run of regions.
-__global__ void __launch_bounds__(1024) k_wf_order(const unsigned* __restrict__ cost, int n, float hot, int blocks, int* __restrict__ order)
+// Three small launches: the n regions are cut into 16 * WF_ORDER_BLOCKS contiguous runs, one per wave;
+//   k_wf_order_count    regions of each run per bin
+//   k_wf_order_offsets  where each run's regions of each bin go (one block)
+//   k_wf_order_place    every region into its place
+// (as one block of 16 waves the sort took 0.11 ms per 4K frame, a sixtieth of the launch it serves: three
+// passes of some hundred instructions per 64 regions are work for more than one CU.)
+#define WF_ORDER_BLOCKS 16
+#define WF_ORDER_RUNS (16 * WF_ORDER_BLOCKS)
+
+// The bin of region i.  Only the regions a launch by index would end up waiting for are moved to the front:
+// region i of n starts when about i / n of the launch is over (the launch takes the sum of the durations over
+// the blocks), and matters if it would still be running near the end - if it takes `hot` times what is left by
+// then, or longer.  Everything else stays in index order behind them, in the last bin.  (Sorting all regions by
+// duration puts the expensive ones on the GPU at the same time, where they take longer than mixed with cheap
+// ones: lego 4K 3.75 ms by index, 4.0 ms sorted; final 4K: the tail gone and nearly as much lost before it.)
+struct WfOrderRule {
+    float left_per_region; // hot * (sum of the durations / blocks) / n
+    int   n;
+};
+__device__ __forceinline__ WfOrderRule wf_order_rule(const WfCounters* ctr, int n, float hot, int blocks)
 {
-    __shared__ int                s_at[16][WF_ORDER_BINS]; // first the count of a wave's regions per bin, then where its next one goes
-    __shared__ unsigned long long s_sum;
-    const int                     t = threadIdx.x, w = t >> 6, lane = t & 63;
+    WfOrderRule r;
+    r.left_per_region = (float)((double)ctr->cost_sum / (double)max(blocks, 1)) * hot / (float)max(n, 1);
+    r.n = n;
+    return r;
+}
+__device__ __forceinline__ int wf_order_bin_of(const WfOrderRule& r, unsigned c, int i)
+{
+    return (float)c >= r.left_per_region * (float)(r.n - i) ? min(wf_order_bin(c), WF_ORDER_BINS - 2) : WF_ORDER_BINS - 1;
+}
+__device__ __forceinline__ void wf_order_run(int n, int& lo, int& hi) // the run of this wave
+{
+    const int per = ((n + WF_ORDER_RUNS - 1) / WF_ORDER_RUNS + 63) & ~63; // whole rounds of 64
+    const int run = blockIdx.x * 16 + (threadIdx.x >> 6);
+    lo = min(run * per, n), hi = min(lo + per, n);
+}
+
+__global__ void __launch_bounds__(1024)
+k_wf_order_count(const unsigned* __restrict__ cost, int n, float hot, int blocks, const WfCounters* __restrict__ ctr,
+                 int* __restrict__ at) // [WF_ORDER_RUNS][WF_ORDER_BINS]
+{
+    __shared__ int s_at[16][WF_ORDER_BINS];
+    const int      t = threadIdx.x, w = t >> 6, lane = t & 63;
     for (int i = t; i < 16 * WF_ORDER_BINS; i += 1024) (&s_at[0][0])[i] = 0;
-    if (t == 0) s_sum = 0;
     __syncthreads();
-    const int per = ((n + 15) / 16 + 63) & ~63; // regions per wave, whole rounds of 64
-    const int lo = min(w * per, n), hi = min(lo + per, n);
-    {
-        unsigned long long mine = 0;
-        for (int i = lo + lane; i < hi; i += 64) mine += cost[i];
-        for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
-        if (lane == 0) atomicAdd(&s_sum, mine);
+    const WfOrderRule rule = wf_order_rule(ctr, n, hot, blocks);
+    int               lo, hi;
+    wf_order_run(n, lo, hi);
+    for (int i0 = lo; i0 < hi; i0 += 64) { // (nearly every region stays where it is: counted by a ballot, not by 64 atomics on one word)
+        const int                i = i0 + lane;
+        const int                b = i < hi ? wf_order_bin_of(rule, cost[i], i) : -1;
+        const unsigned long long stay = __ballot(b == WF_ORDER_BINS - 1);
+        if (lane == 0) s_at[w][WF_ORDER_BINS - 1] += __popcll(stay);
+        if (b >= 0 && b != WF_ORDER_BINS - 1) atomicAdd(&s_at[w][b], 1);
     }
     __syncthreads();
-    // Only the regions a launch by index would end up waiting for are moved to the front: region i of n starts
-    // when about i / n of the launch is over (the launch takes the sum of the durations over the blocks), and
-    // matters if it would still be running near the end - if it takes `hot` times what is left by then, or
-    // longer.  Everything else stays in index order behind them.  (Sorting all regions by duration puts the
-    // expensive ones on the GPU at the same time, where they take longer than mixed with cheap ones: lego
-    // 4K 3.75 ms by index, 4.0 ms sorted; final 4K: the tail gone and nearly as much lost before it.)
-    const float left_per_region = (float)((double)s_sum / (double)max(blocks, 1)) * hot / (float)max(n, 1);
-    auto bin = [&](unsigned c, int i) {
-        return (float)c >= left_per_region * (float)(n - i) ? min(wf_order_bin(c), WF_ORDER_BINS - 2) : WF_ORDER_BINS - 1;
-    };
-    for (int i = lo + lane; i < hi; i += 64) atomicAdd(&s_at[w][bin(cost[i], i)], 1);
-    __syncthreads();
+    for (int i = t; i < 16 * WF_ORDER_BINS; i += 1024) at[(size_t)blockIdx.x * 16 * WF_ORDER_BINS + i] = (&s_at[0][0])[i];
+}
+
+__global__ void __launch_bounds__(1024) k_wf_order_offsets(int* __restrict__ at)
+{
+    // thread = (segment of WF_ORDER_RUNS / 8 runs, bin): its runs' counts are fetched together, not one after the other
+    constexpr int  SEG = WF_ORDER_RUNS / 8;
+    __shared__ int s_seg[8][WF_ORDER_BINS];
     __shared__ int s_total[WF_ORDER_BINS];
-    if (t < WF_ORDER_BINS) { // within bin t: where each wave's regions start
-        int run = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int c = s_at[k][t];
-            s_at[k][t] = run;
-            run += c;
+    const int      b = threadIdx.x & (WF_ORDER_BINS - 1), g = threadIdx.x / WF_ORDER_BINS;
+    int            c[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) c[k] = at[(g * SEG + k) * WF_ORDER_BINS + b];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) { // within the segment: where each run's regions of bin b start
+        const int v = c[k];
+        c[k] = run;
+        run += v;
+    }
+    s_seg[g][b] = run;
+    __syncthreads();
+    if (g == 0) {
+        int tot = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int v = s_seg[k][b];
+            s_seg[k][b] = tot;
+            tot += v;
         }
-        s_total[t] = run;
+        s_total[b] = tot;
     }
     __syncthreads();
-    if (t < WF_ORDER_BINS) { // plus all regions of the bins before it
-        int before = 0;
-        for (int b = 0; b < t; ++b) before += s_total[b];
-        for (int k = 0; k < 16; ++k) s_at[k][t] += before;
-    }
+    int before = s_seg[g][b]; // the segments before this one, plus all regions of the bins before b
+    for (int k = 0; k < b; ++k) before += s_total[k];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) at[(g * SEG + k) * WF_ORDER_BINS + b] = c[k] + before;
+}
+
+// Stable: regions of one bin keep their index order, so neighbouring regions - which walk the same part of the
+// tree - are still handed out one after the other.
+__global__ void __launch_bounds__(1024)
+k_wf_order_place(const unsigned* __restrict__ cost, int n, float hot, int blocks, const WfCounters* __restrict__ ctr,
+                 const int* __restrict__ at, int* __restrict__ order)
+{
+    __shared__ int s_at[16][WF_ORDER_BINS];
+    const int      t = threadIdx.x, w = t >> 6, lane = t & 63;
+    for (int i = t; i < 16 * WF_ORDER_BINS; i += 1024) (&s_at[0][0])[i] = at[(size_t)blockIdx.x * 16 * WF_ORDER_BINS + i];
     __syncthreads();
+    const WfOrderRule rule = wf_order_rule(ctr, n, hot, blocks);
+    int               lo, hi;
+    wf_order_run(n, lo, hi);
     for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int  i = i0 + lane;
-        const bool valid = i < hi;
-        const int  b = valid ? bin(cost[i], i) : -1;
+        const int          i = i0 + lane;
+        const bool         valid = i < hi;
+        const int          b = valid ? wf_order_bin_of(rule, cost[i], i) : -1;
         unsigned long long todo = __ballot(valid);
         while (todo) { // the lanes of one bin take consecutive places, in lane order
             const int                leader = __ffsll((long long)todo) - 1;
@@ -1444,8 +1503,11 @@ k_wf_pipeline(WfLaunch)
             }
         }
         WF_TL(14);
-        if (threadIdx.x == 0 && wf_args()->cost) // (100 MHz ticks; a region takes 20 us to a few ms)
-            wf_args()->cost[r] = (unsigned)min(wall_clock64() - t_region, 0xffffffffull) + 1u;
+        if (threadIdx.x == 0 && wf_args()->cost) { // (100 MHz ticks; a region takes 20 us to a few ms)
+            const unsigned took = (unsigned)min(wall_clock64() - t_region, 0xfffffffeull) + 1u;
+            wf_args()->cost[r] = took;
+            atomicAdd(&wf_args()->B.ctr->cost_sum, (unsigned long long)took);
+        }
     }
 #ifdef WF_SECT
     __syncthreads();

@@ -518,7 +518,7 @@ def test_render_paths_agree(P, oracle, monkeypatch):
 
 def test_region_order_from_the_last_frame_changes_nothing(P, monkeypatch):
     """From the second frame of a shape on, the single launch hands its regions out in the order of the
-    durations the frame before measured (k_wf_order).  That is a hint about when a region runs, never about
+    durations the frame before measured (k_wf_order_*).  That is a hint about when a region runs, never about
     what it renders: frames 2 and 3 of a scene equal its first frame and the frame of a scene that never
     reorders (RT_WF_FEEDBACK=0), bit for bit, also across a change of shape and for one rank's share of a deal."""
     monkeypatch.delenv("RT_WF_FEEDBACK", raising=False)
