@@ -118,7 +118,7 @@ k_check_hits(DScene S, long long n, const float* __restrict__ org, const float* 
         HitRec   h;
         nc = 1;
         const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
-        if (tri) tri[i] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w) : -1;
+        if (tri) tri[i] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 2].w) : -1;
         if (a) a[i] = h.a;
         if (b) b[i] = h.b;
         if (t) t[i] = h.t;
@@ -185,7 +185,7 @@ k_centre(DScene S, DParams P, long long n_slots, float* rgb, float* depth, int* 
             HitRec h;
             nc = 1;
             const bool got = kd_trace<false>(S, o, d, s_stack + threadIdx.x, RT_BLOCK, h, nt, nn);
-            if (tri) tri[p] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w) : -1;
+            if (tri) tri[p] = got ? __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 2].w) : -1;
             hit_flag[slot] = got ? 1 : 0;
             if (!got) {
                 rgb[3 * p] = clamp01(P.bg[0]), rgb[3 * p + 1] = clamp01(P.bg[1]),
@@ -479,6 +479,7 @@ struct RtScene {
     void*   d_nodes = nullptr;
     void*   d_tris = nullptr;
     void*   d_edges = nullptr;
+    void*   d_heads = nullptr;
     void*   d_shade = nullptr;
     void*   d_info = nullptr;
     void*   d_texcoords = nullptr;
@@ -590,7 +591,7 @@ extern "C" void rt_scene_destroy(RtScene* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->d_nodes, s->d_tris,    s->d_shade, s->d_info,  s->d_texcoords, s->d_mats,
-                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges, s->wf_cost, s->wf_order, s->wf_order_at};
+                    s->d_texinfo, s->d_texels, s->d_ctr,  s->d_flags, s->d_samples, s->d_rank, s->wf_mem, s->d_params, s->d_knodes, s->d_stk_spill, s->d_edges, s->d_heads, s->wf_cost, s->wf_order, s->wf_order_at};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
@@ -935,7 +936,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         const char*  lt_env = getenv("RT_KD_LEAF");
         const char*  ci_env = getenv("RT_KD_CI");
         KdSplitParams prm;
-        prm.leaf_target = lt_env ? atoi(lt_env) : 6; // do not split leaves at or below this size (4 until the plane heads made a test cheaper than a node step)
+        prm.leaf_target = lt_env ? atoi(lt_env) : 12; // do not split leaves at or below this size (4 until the plane heads, two at a time, made a test far cheaper than a node step)
         prm.c_trav = 1.0, prm.c_isect = ci_env ? atof(ci_env) : 3.0;
         for (int a = 0; a < 3; ++a) {
             const double pad = 0.05 * (hi[a] - lo[a]) + 1e-3;
@@ -1061,12 +1062,18 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         depth_of.push_back(0);
     }
     std::vector<DNode>  nodes(lists.size());
-    std::vector<float4> slots, edges;
+    std::vector<float4> slots, edges, heads;
+    const float4        zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (size_t k = 0; k < lists.size(); ++k) {
         DNode     dn;
         const int axis = axis_of[k];
         dn.left = new_left[k];
         dn.split = dn.left >= 0 ? split_of[k] : 0.0f;
+        if (!lists[k].empty() && (slots.size() / RT_SLOT_F4) % 2 == 1) { // lists start at even slots: heads go in pairs
+            slots.insert(slots.end(), RT_SLOT_F4, zero4);
+            edges.insert(edges.end(), 3, zero4);
+            heads.push_back(zero4);
+        }
         dn.tri_off = (int)(slots.size() / RT_SLOT_F4);
         if (lists[k].size() >= (1u << 28))
             return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: node triangle list too long");
@@ -1081,7 +1088,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             volatile float p1 = e1x * e2y, p4 = e1z * e2y;
             float          idx;
             memcpy(&idx, &t, 4);
-            // the plane head (tri_head_keep): (e1 x e2, (e1 x e2) . v2) / B in double, rounded once
+            // the plane head (tri_heads_keep): (e1 x e2, (e1 x e2) . v2) / B in double, rounded once
             const double a1[3] = {(double)e1x, (double)e1y, (double)e1z}, a2[3] = {(double)e2x, (double)e2y, (double)e2z};
             double       nrm[3], B = 0.0;
             for (int c = 0; c < 3; ++c) {
@@ -1118,7 +1125,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
                 }
             }
             edges.push_back(g0), edges.push_back(g1), edges.push_back(g2);
-            slots.push_back(hd);
+            heads.push_back(hd); // (interleaved in pairs below)
             slots.push_back(make_float4(e1x, e1y, e1z, e2x));
             slots.push_back(make_float4(e2y, e2z, v2[0], v2[1]));
             slots.push_back(make_float4(v2[2], p1, p4, idx));
@@ -1127,6 +1134,12 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     }
     if (slots.size() / RT_SLOT_F4 >= (1u << 28))
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many triangle references");
+    if (heads.size() % 2 == 1) heads.push_back(zero4);
+    for (size_t p2 = 0; p2 + 1 < heads.size(); p2 += 2) { // n0 k0, n1 k1  ->  n0.x n1.x n0.y n1.y, n0.z n1.z k0 k1
+        const float4 a = heads[p2], b = heads[p2 + 1];
+        heads[p2] = make_float4(a.x, b.x, a.y, b.y);
+        heads[p2 + 1] = make_float4(a.z, b.z, a.w, b.w);
+    }
     std::vector<uint2> knodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); ++k) {
         const DNode& n = nodes[k];
@@ -1203,7 +1216,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         if (const char* h = getenv("RT_WF_HOT")) s->wf_hot = (float)atof(h);
     }
     int rc;
-    if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) || (rc = upload(&s->d_edges, edges, &s->bytes)) ||
+    if ((rc = upload(&s->d_nodes, nodes, &s->bytes)) || (rc = upload(&s->d_tris, slots, &s->bytes)) || (rc = upload(&s->d_edges, edges, &s->bytes)) || (rc = upload(&s->d_heads, heads, &s->bytes)) ||
         (rc = upload(&s->d_shade, shade, &s->bytes)) || (rc = upload(&s->d_info, info, &s->bytes)) ||
         (rc = upload(&s->d_texcoords, texcoords, &s->bytes)) ||
         (rc = upload(&s->d_mats, mats, &s->bytes)) || (rc = upload(&s->d_texinfo, texinfo, &s->bytes)) ||
@@ -1221,6 +1234,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.nodes = (const DNode*)s->d_nodes;
     s->d.tris = (const float4*)s->d_tris;
     s->d.edges = (const float4*)s->d_edges;
+    s->d.heads = (const float4*)s->d_heads;
     s->d.tri_shade = (const float4*)s->d_shade;
     s->d.tri_info = (const int4*)s->d_info;
     s->d.texcoords = (const float*)s->d_texcoords;
@@ -1247,7 +1261,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
             for (int b = 0; b < 4; ++b) h = (h ^ ((v >> (8 * b)) & 0xffu)) * 1099511628211ull;
         };
         for (const uint2& k : knodes) mix(k.x), mix(k.y);
-        for (size_t i = 0; i < slots.size() / RT_SLOT_F4; ++i) mix((uint32_t)__builtin_bit_cast(int32_t, slots[RT_SLOT_F4 * i + 3].w));
+        for (size_t i = 0; i < slots.size() / RT_SLOT_F4; ++i) mix((uint32_t)__builtin_bit_cast(int32_t, slots[RT_SLOT_F4 * i + 2].w));
         s->tree_hash = h;
     }
     s->tree_ms = (float)tree_ms, s->tree_on_gpu = tree_on_gpu ? 1 : 0;
@@ -1402,6 +1416,7 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
                 d[12], (double)d[12] / (double)(d[8] ? d[8] : 1), d[13], (double)d[13] / (double)(d[9] ? d[9] : 1));
         fprintf(stderr, "diag: edge records: %llu wave trips with a lane past them (%.3f of the trips past the head), %llu such lanes\n",
                 d[14], (double)d[14] / (double)(d[8] ? d[8] : 1), d[15]);
+        fprintf(stderr, "diag: leaves with triangles visited by waves: %llu; trips of the triangle loop if it took two triangles at a time: %llu\n", d[10], d[11]);
         fprintf(stderr, "diag: shadow rays %llu, occluded %llu, their tests %llu and node steps %llu\n", d[4], d[5], d[6], d[7]);
     }
 #endif

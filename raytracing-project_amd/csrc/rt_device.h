@@ -32,24 +32,29 @@ struct DNode {
     int32_t cnt_axis; // triangle count | axis << 28
 };
 
-// Triangle slots: every node's list in node order; a triangle may be listed by
-// several leaves.  Ties in t go to the triangle the reference's walk would have
-// tested last on its root-to-leaf path (raytracing.cpp:311-338), recorded per
-// triangle in DScene::tri_rank.  Four float4 (64 bytes, half a cache line) per slot:
-//   hd = n.x n.y n.z k            the triangle's plane, scaled (tri_head_keep)
-//   q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
-//   q1 = e2.y e2.z v2.x v2.y
-//   q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
+// Triangle slots: every node's list in node order; a triangle may be listed by several leaves.  A list starts at
+// an even slot (an unused slot fills the gap).  Ties in t go to the triangle the reference's walk would have
+// tested last on its root-to-leaf path (raytracing.cpp:311-338), recorded per triangle in DScene::tri_rank.
+// Per slot, in three arrays that a walk reads in this order, each only for what the one before let through:
+//   heads  one float4 per slot, the plane heads of slots 2p and 2p + 1 interleaved (tri_heads_keep):
+//            heads[2p]     = n0.x n1.x n0.y n1.y
+//            heads[2p + 1] = n0.z n1.z k0   k1        (n, k: the triangle's plane, scaled; zero for no triangle)
+//   edges  three float4: (ga, ka) s, (gb, kb) s, (s, -, -, -)      (tri_edges_keep)
+//   tris   three float4, what the exact test takes:
+//            q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
+//            q1 = e2.y e2.z v2.x v2.y
+//            q2 = v2.z e1.x*e2.y e1.z*e2.y bits(original triangle index)
 // Compact form of the same tree for the wavefront trace kernels, 8 bytes per node:
 //   inner: x = bits(split plane), y = axis << 30 | index of the left child
 //   leaf : x = first triangle slot, y = 3 << 30 | triangle count
 // (only built when inner nodes carry no triangles of their own).
-#define RT_SLOT_F4 4 // float4 per triangle slot
+#define RT_SLOT_F4 3 // float4 per triangle slot in DScene::tris
 struct DScene {
     const DNode*   nodes;
     const uint2*   knodes;
     const float4*  tris;
-    const float4*  edges;     // per slot: 3 float4 = (ga, ka) s, (gb, kb) s, (s, -, -, -), see tri_edges_keep
+    const float4*  heads;
+    const float4*  edges;
     const float4*  tri_shade; // per original triangle: 3 float4 = nA nB nC (xyz) + w: material, t0|t1.., see pack
     const int4*    tri_info;  // per original triangle: material, t0, t1, t2
     const float*   texcoords; // 3 per entry
@@ -62,7 +67,7 @@ struct DScene {
     // ones in stk_spill (per block: [entry - stk_cap][thread]); an entry is (node, bits of the entry t)
     uint2*          stk_spill;
     int32_t         stk_cap;
-    float           vert_l1; // largest |x| + |y| + |z| over the vertices (tri_head_keep's bound on n . v2)
+    float           vert_l1; // largest |x| + |y| + |z| over the vertices (tri_heads_keep's bound on n . v2)
 };
 
 struct DParams {
@@ -364,21 +369,62 @@ __device__ __forceinline__ void tri_head_bounds(f3 o, f3 d, float vert_l1, float
     eN = so < huge ? fmaxf(so * 1.9073486e-6f, floor_) : inf;
 }
 
-__device__ __forceinline__ bool tri_head_keep(const float4 hd, f3 o, f3 d, float eD, float eN, float lo_s,
-                                              float hi_s, float& Dh, float& Nh)
+// Two plane heads at a time, in the halves of packed FP32 operations (v_pk_fma_f32 and friends: two separately
+// rounded results per instruction, a scalar operand taken from either half of a register pair for both).  A wave
+// runs the triangle loop as long as its fullest leaf, four trips on average; in pairs it is two, of 24 vector
+// instructions for two heads against 18 for one.  The ray travels as three register pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define RT_PK(name, text)                                                                                     \
+    __device__ __forceinline__ v2f name(v2f a, v2f b) { v2f r; asm(text : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define RT_PK3(name, text)                                                                                    \
+    __device__ __forceinline__ v2f name(v2f a, v2f b, v2f c) { v2f r; asm(text : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_PK(pk_mul_lo, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]")                        // a * b.lo
+RT_PK(pk_mul_hi, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]")           // a * b.hi
+RT_PK(pk_add_lo, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]")                        // a + b.lo
+RT_PK(pk_sub_lo, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]") // a - b.lo
+RT_PK(pk_add_hi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]")           // a + b.hi
+RT_PK(pk_rsub_hi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]") // b.hi - a
+RT_PK3(pk_fma_lo, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]")                 // a * b.lo + c
+RT_PK3(pk_fma_hi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]")  // a * b.hi + c
+RT_PK3(pk_fms_lo, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]") // a * b.lo - c
+#undef RT_PK
+#undef RT_PK3
+
+struct RayPairs {
+    v2f oxy, ozdx, dyz; // (o.x, o.y) (o.z, d.x) (d.y, d.z)
+};
+
+// h0 = n0.x n1.x n0.y n1.y, h1 = n0.z n1.z k0 k1; eDN = (eD, eN); loh = (lo_s, hi_s), lo_s = lo / 1.000001,
+// hi_s = hi * 1.000001 (the rounding of the reference's quotient).  D, N: the heads' D / B and N / B.
+__device__ __forceinline__ void tri_heads_keep(const float4 h0, const float4 h1, const RayPairs& r, v2f eDN, v2f loh,
+                                               v2f& D, v2f& N, bool& keep0, bool& keep1)
 {
-    // lo_s = lo / 1.000001, hi_s = hi * 1.000001 (the rounding of the reference's quotient)
-    Dh = __builtin_fmaf(hd.x, d.x, __builtin_fmaf(hd.y, d.y, hd.z * d.z));
-    Nh = __builtin_fmaf(hd.x, o.x, __builtin_fmaf(hd.y, o.y, __builtin_fmaf(hd.z, o.z, -hd.w)));
-    const float lowD = fabsf(Dh) - eD, upD = fabsf(Dh) + eD; // |D| / B lies in [lowD, upD]
+    const v2f nx = {h0.x, h0.y}, ny = {h0.z, h0.w}, nz = {h1.x, h1.y}, kk = {h1.z, h1.w};
+    D = pk_fma_hi(nx, r.ozdx, pk_fma_lo(ny, r.dyz, pk_mul_hi(nz, r.dyz)));
+    N = pk_fma_lo(nx, r.oxy, pk_fma_hi(ny, r.oxy, pk_fms_lo(nz, r.ozdx, kk)));
+    const v2f aD = {fabsf(D.x), fabsf(D.y)};
+    const v2f lowD = pk_sub_lo(aD, eDN), upD = pk_add_lo(aD, eDN); // |D| / B lies in [lowD, upD]
     // nq = N sign(D) = -t |D|
-    const float nq = __uint_as_float(__float_as_uint(Nh) ^ (__float_as_uint(Dh) & 0x80000000u));
+    const v2f nq = {__uint_as_float(__float_as_uint(N.x) ^ (__float_as_uint(D.x) & 0x80000000u)),
+                    __uint_as_float(__float_as_uint(N.y) ^ (__float_as_uint(D.y) & 0x80000000u))};
+    const v2f far_ = pk_add_hi(nq, eDN), near_ = pk_rsub_hi(nq, eDN); // nq + eN, eN - nq
+    const v2f hiD = pk_mul_hi(upD, loh), loD = pk_mul_lo(lowD, loh);
     // (no short circuits: one straight run of instructions, no branch around half of it)
-    const int sure = lowD > 0.0f;
-    const int behind = nq > eN;                 // t < 0
-    const int beyond = nq + eN < -(hi_s * upD); // t > hi
-    const int before = eN - nq < lo_s * lowD;   // t < lo
-    return !(sure & (behind | beyond | before));
+    const float eN = eDN.y;
+    {
+        const int sure = lowD.x > 0.0f;
+        const int behind = nq.x > eN;        // t < 0
+        const int beyond = far_.x < -hiD.x;  // t > hi
+        const int before = near_.x < loD.x;  // t < lo
+        keep0 = !(sure & (behind | beyond | before));
+    }
+    {
+        const int sure = lowD.y > 0.0f;
+        const int behind = nq.y > eN;
+        const int beyond = far_.y < -hiD.y;
+        const int before = near_.y < loD.y;
+        keep1 = !(sure & (behind | beyond | before));
+    }
 }
 
 // The edge record of a slot, and what it decides.  A ray that crosses the triangle's plane inside the cell (the
@@ -447,14 +493,14 @@ __device__ __forceinline__ bool kd_trace(const DScene& S, f3 o, f3 dst, uint2* s
         const int cnt = nd.cnt_axis & 0x0fffffff;
         for (int i = 0; i < cnt; ++i) {
             const int    slot = nd.tri_off + i;
-            const float4 q0 = S.tris[RT_SLOT_F4 * slot + 1], q1 = S.tris[RT_SLOT_F4 * slot + 2], q2 = S.tris[RT_SLOT_F4 * slot + 3];
+            const float4 q0 = S.tris[RT_SLOT_F4 * slot], q1 = S.tris[RT_SLOT_F4 * slot + 1], q2 = S.tris[RT_SLOT_F4 * slot + 2];
             float        a, b, t;
             ++n_tests;
             if (tri_test(q0, q1, q2, o, d, minT, a, b, t)) {
                 if (ANY) return true;
                 bool take = t != minT || h.slot < 0;
                 if (!take) { // equal t: keep the one the reference's test order ends with
-                    const int cur = __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 3].w);
+                    const int cur = __float_as_int(S.tris[RT_SLOT_F4 * h.slot + 2].w);
                     take = S.tri_rank[__float_as_int(q2.w)] > S.tri_rank[cur];
                 }
                 if (take) h.slot = slot, h.a = a, h.b = b, minT = t;
@@ -557,7 +603,7 @@ __device__ __forceinline__ void trace_sample(const DScene& S, const DParams& P, 
         ++n_closest;
         const bool got = kd_trace<false>(S, r.o, r.d, stk, stride, hit, n_tests, n_nodes);
         int orig = -1;
-        if (got) orig = __float_as_int(S.tris[RT_SLOT_F4 * hit.slot + 3].w);
+        if (got) orig = __float_as_int(S.tris[RT_SLOT_F4 * hit.slot + 2].w);
         if (first) {
             minT_out = hit.t;
             tri_out = orig;

@@ -281,8 +281,13 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 iy = d.y != 0.0f ? __builtin_amdgcn_rcpf(d.y) : big,
                 iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
     const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
-    float       eD, eN; // the plane heads' error bounds for this ray
-    tri_head_bounds(o, d, S.vert_l1, eD, eN);
+    v2f eDN; // the plane heads' error bounds for this ray
+    {
+        float eD, eN;
+        tri_head_bounds(o, d, S.vert_l1, eD, eN);
+        eDN = v2f{eD, eN};
+    }
+    const RayPairs rp = {v2f{o.x, o.y}, v2f{o.z, d.x}, v2f{d.y, d.z}};
     for (;;) {
         uint2 nd = S.knodes[node];
         if (COUNT) ++n_nodes;
@@ -318,68 +323,78 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         const int cnt = (int)(nd.y & 0x3fffffffu);
         const int first = (int)nd.x;
 #ifdef WF_DIAG
-        if (COUNT) atomicAdd(&g_diag[cnt == 0 ? 2 : 3], 1ull);
+        if (COUNT) {
+            atomicAdd(&g_diag[cnt == 0 ? 2 : 3], 1ull);
+            int mx_ = cnt; // the longest list among the wave's lanes: the trips of the triangle loop; in pairs it would be half
+            for (int d_ = 32; d_ > 0; d_ >>= 1) mx_ = max(mx_, __shfl_xor(mx_, d_));
+            const unsigned long long a_ = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && mx_ > 0)
+                atomicAdd(&g_diag[10], 1ull), atomicAdd(&g_diag[11], (unsigned long long)((mx_ + 1) / 2));
+        }
 #endif
         const float lo = tmin_e * 0.9999f, hi = ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f);
-        const float lo_s = lo * 0.999999f;
-        float       hi_s = hi * 1.000001f;
-        for (int i = 0; i < cnt; ++i) {
-            const int     slot = first + i;
-            const float4* rec = S.tris + (size_t)RT_SLOT_F4 * slot;
-            float4        hd = rec[0];
-            // (the rest of the slot asked for with the head and waited for only by survivors: 8.08 vs 7.67 ms)
-            if (COUNT) ++n_tests;
+        v2f         loh = {lo * 0.999999f, hi * 1.000001f}; // the stretch of the ray inside the cell, margins applied
+        for (int i = 0; i < cnt; i += 2) { // slots first + i and first + i + 1 (a list starts at an even slot)
+            const float4* hp = S.heads + (first + i);
+            float4        h0 = hp[0], h1 = hp[1];
+            // (the rest of a slot asked for with its head and waited for only by survivors: 8.08 vs 7.67 ms)
+            const bool two = i + 1 < cnt;
+            if (COUNT) n_tests += two ? 2u : 1u;
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
 #endif
-            // (the head as one 16-byte load, complete here: the compiler would otherwise fetch its last word
-            // later, behind a wait for the whole slot)
-            asm volatile("" ::"v"(hd.x), "v"(hd.y), "v"(hd.z), "v"(hd.w));
-            float Dh, Nh;
-            const bool keep = tri_head_keep(hd, o, d, eD, eN, lo_s, hi_s, Dh, Nh);
+            // (the heads as two 16-byte loads, complete here: the compiler would otherwise fetch words of them
+            // later, behind a wait for a whole slot)
+            asm volatile("" ::"v"(h0.x), "v"(h0.y), "v"(h0.z), "v"(h0.w), "v"(h1.x), "v"(h1.y), "v"(h1.z), "v"(h1.w));
+            v2f  D2, N2;
+            bool keep0, keep1;
+            tri_heads_keep(h0, h1, rp, eDN, loh, D2, N2, keep0, keep1);
+            keep1 = keep1 && two;
 #ifdef WF_DIAG
             if (COUNT) {
-                const unsigned long long a_ = __ballot(1), m_ = __ballot(keep);
-                if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[8], 1ull), atomicAdd(&g_diag[9], (unsigned long long)__popcll(m_));
+                const unsigned long long a_ = __ballot(1), m0_ = __ballot(keep0), m1_ = __ballot(keep1);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1)
+                    atomicAdd(&g_diag[8], (m0_ ? 1ull : 0ull) + (m1_ ? 1ull : 0ull)), atomicAdd(&g_diag[9], (unsigned long long)(__popcll(m0_) + __popcll(m1_)));
             }
 #endif
-            if (!keep) continue;
-#ifndef WF_NO_EDGES
-            {
-                const float4* er = S.edges + (size_t)3 * slot;
-                const float4  E0 = er[0], E1 = er[1];
-                const float   es = er[2].x;
-                const bool    keep2 = tri_edges_keep(E0, E1, es, o, d, Dh, Nh, eD, eN);
+            if (!(keep0 || keep1)) continue;
+            // what follows a head that lets the ray through: the edge record, then the exact test
+            auto candidate = [&](const int slot, const float Dh, const float Nh) -> bool {
+                {
+                    const float4* er = S.edges + (size_t)3 * slot;
+                    const float4  E0 = er[0], E1 = er[1];
+                    const float   es = er[2].x;
+                    const bool    keep2 = tri_edges_keep(E0, E1, es, o, d, Dh, Nh, eDN.x, eDN.y);
+#ifdef WF_DIAG
+                    if (COUNT) {
+                        const unsigned long long a_ = __ballot(1), m_ = __ballot(keep2);
+                        if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[14], 1ull), atomicAdd(&g_diag[15], (unsigned long long)__popcll(m_));
+                    }
+#endif
+                    if (!keep2) return false;
+                }
+                const float4* rec = S.tris + (size_t)RT_SLOT_F4 * slot;
+                const float4  q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                float         a, b, t;
 #ifdef WF_DIAG
                 if (COUNT) {
-                    const unsigned long long a_ = __ballot(1), m_ = __ballot(keep2);
-                    if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && m_) atomicAdd(&g_diag[14], 1ull), atomicAdd(&g_diag[15], (unsigned long long)__popcll(m_));
+                    float a_, b_, t_;
+                    const bool ok_ = tri_test_line(q0, q1, q2, o, d, minT, a_, b_, t_);
+                    const unsigned long long m_ = __ballot(1), h_ = __ballot(ok_);
+                    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1 && h_) atomicAdd(&g_diag[12], 1ull), atomicAdd(&g_diag[13], (unsigned long long)__popcll(h_));
                 }
 #endif
-                if (!keep2) continue;
-            }
-#endif
-            const float4 q0 = rec[1], q1 = rec[2], q2 = rec[3];
-            float a, b, t;
-#ifdef WF_DIAG
-            if (COUNT) {
-                float a_, b_, t_;
-                const bool ok_ = tri_test_line(q0, q1, q2, o, d, minT, a_, b_, t_);
-                const unsigned long long m_ = __ballot(1), h_ = __ballot(ok_);
-                if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1 && h_) atomicAdd(&g_diag[12], 1ull), atomicAdd(&g_diag[13], (unsigned long long)__popcll(h_));
-            }
-#endif
-#ifdef WF_TRI_STAGED
-            if (tri_test_cell(q0, q1, q2, o, d, minT, lo, ANY ? RT_FLT_MAX : fminf(minT, tmax_e * 1.0001f), a, b, t)) {
-#else
-            if (tri_test_line(q0, q1, q2, o, d, minT, a, b, t)) {
-#endif
-                if (ANY) return true;
-                const int orig = __float_as_int(q2.w);
-                bool      take = t != minT || best_orig < 0;
-                if (!take) take = S.tri_rank[orig] > S.tri_rank[best_orig];
-                if (take) h.a = a, h.b = b, minT = t, best_orig = orig, hi_s = fminf(hi_s, t * 1.000001f);
-            }
+                if (tri_test_line(q0, q1, q2, o, d, minT, a, b, t)) {
+                    if (ANY) return true;
+                    const int orig = __float_as_int(q2.w);
+                    bool      take = t != minT || best_orig < 0;
+                    if (!take) take = S.tri_rank[orig] > S.tri_rank[best_orig];
+                    if (take) h.a = a, h.b = b, minT = t, best_orig = orig, loh.y = fminf(loh.y, t * 1.000001f);
+                }
+                return false;
+            };
+            if (keep0 && candidate(first + i, D2.x, N2.x)) return true;
+            if (keep1 && candidate(first + i + 1, D2.y, N2.y)) return true;
         }
         // A pending subtree starts where the cell above it on the stack ends, give or take the
         // margins: entry t of the top entry = tmax_e / (1 + eps), and every deeper entry starts

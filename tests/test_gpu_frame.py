@@ -42,11 +42,14 @@ def test_scene_info(P):
     assert i["render_path"] == 0         # the single persistent launch over ray queues
 
 
-def test_scene_beyond_65535_nodes_renders_on_the_pipeline(P, oracle):
-    """fin.obj (13444 triangles): its refined device tree has more nodes than a 16-bit index names;
-    traversal stack entries carry 32-bit nodes, so the scene stays on the ray-queue pipeline, with
-    its refinement run to the end.  A reduced frame against the oracle, refraction included."""
+def test_scene_beyond_65535_nodes_renders_on_the_pipeline(P, oracle, monkeypatch):
+    """fin.obj (13444 triangles) refined down to leaves of four triangles: the device tree has more nodes
+    than a 16-bit index names; traversal stack entries carry 32-bit nodes, so the scene stays on the
+    ray-queue pipeline, with its refinement run to the end.  A reduced frame against the oracle, refraction
+    included."""
+    monkeypatch.setenv("RT_KD_LEAF", "4")      # (read when the scene is created; the default leaves are larger)
     hs, gs, m, lights = _host_gpu(P, "fin")
+    monkeypatch.delenv("RT_KD_LEAF")
     i = gs.info()
     assert i["n_nodes"] > 65535 and i["render_path"] == 0 and i["n_triangles"] == 13444
     W, H = 240, 135
