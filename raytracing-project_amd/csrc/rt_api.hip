@@ -1416,7 +1416,7 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
                 d[12], (double)d[12] / (double)(d[8] ? d[8] : 1), d[13], (double)d[13] / (double)(d[9] ? d[9] : 1));
         fprintf(stderr, "diag: edge records: %llu wave trips with a lane past them (%.3f of the trips past the head), %llu such lanes\n",
                 d[14], (double)d[14] / (double)(d[8] ? d[8] : 1), d[15]);
-        fprintf(stderr, "diag: leaves with triangles visited by waves: %llu; trips of the triangle loop if it took two triangles at a time: %llu\n", d[10], d[11]);
+        fprintf(stderr, "diag: leaves with triangles visited by waves: %llu; trips of the triangle loop (two triangles each): %llu\n", d[10], d[11]);
         fprintf(stderr, "diag: shadow rays %llu, occluded %llu, their tests %llu and node steps %llu\n", d[4], d[5], d[6], d[7]);
     }
 #endif

@@ -255,72 +255,19 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
 }
 
-// The same test for a walk that knows which stretch [lo, hi] of the ray lies in the cell it is in
-// (margins included).  The walk visits the cells along the ray front to back and every cell lists every
-// triangle that reaches into it, so a triangle whose plane the ray crosses before lo has been met - and
-// tested - in an earlier cell, and one crossed after hi will be met in a later one unless a nearer hit
-// ends the walk first: either way it can be dropped here as soon as D and the numerator of t say so.
-// final.obj, 4K MSAA4: of 1.44 G tests 33 % cross behind the origin, 15 % before the cell, 27 % beyond
-// it and 6 % beyond the closest hit so far; 19 % cross inside the cell.  So t goes first (it went last
-// in tri_test, where only t < 0 and t > minT can be told) and the numerators of a and b are evaluated
-// for a fifth of the tests.  An any-hit walk passes hi = FLT_MAX: a hit beyond the cell ends it.
-// (D and the numerator of t are one expression in d and in c; evaluating the two as the halves of packed
-// FP32 operations brings the first stage from 45 to 38 instructions and changes nothing in the time.)
-__device__ __forceinline__ bool tri_test_cell(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d,
-                                              float minT, float lo, float hi, float& a, float& b, float& t)
-{
-    const float e1x = q0.x, e1y = q0.y, e1z = q0.z, e2x = q0.w, e2y = q1.x, e2z = q1.y;
-    const float cx = o.x - q1.z, cy = o.y - q1.w, cz = o.z - q2.x;
-    const float p1 = q2.y, p4 = q2.z; // e1x*e2y, e1z*e2y
-    const float e2x_dy = e2x * d.y, dx_e1y = d.x * e1y, e2z_dy = e2z * d.y, dz_e1y = d.z * e1y;
-    const float D = p1 * d.z + e2x_dy * e1z + dx_e1y * e2z - p4 * d.x - e2z_dy * e1x - dz_e1y * e2x;
-    const float dt = p1 * cz + (e2x * cy) * e1z + (cx * e1y) * e2z - p4 * cx - (e2z * cy) * e1x -
-                     (cz * e1y) * e2x;
-    // |D| in [2^-40, 2^40] and |numerator| >= 2^-80 keep every quotient below clear of underflow
-    const float aD = fabsf(D);
-    const bool  Dok = aD >= 9.094947e-13f && aD <= 1.0995116e12f;
-    const float tiny = 8.271806e-25f; // 2^-80
-    const float aDm = aD * 1.00001f;  // |n| > bound * aDm  =>  |n / D| > bound after rounding
-    const int   sD = __float_as_int(D);
-    if (Dok) {
-        const float adt = fabsf(dt);
-        if (adt >= tiny) {
-            if ((__float_as_int(dt) ^ sD) >= 0) return false; // dt / D > 0, i.e. t = -(dt / D) < 0
-            if (adt > hi * aDm) return false;                 // t > hi (hi <= minT)
-            if (adt * 1.00001f < lo * aD) return false;       // t < lo
-        }
-    }
-    const float da = (cx * e2y) * d.z + e2x_dy * cz + (d.x * cy) * e2z - (cz * e2y) * d.x -
-                     e2z_dy * cx - (d.z * cy) * e2x;
-    if (Dok) {
-        const bool negA = (__float_as_int(da) ^ sD) < 0; // da / D < 0
-        if (negA ? fabsf(da) >= tiny : fabsf(da) > aDm) return false; // a < 0, or a > 1 (then b < 0 or a + b > 1)
-    }
-    const float db = (e1x * cy) * d.z + (cx * d.y) * e1z + dx_e1y * cz - (e1z * cy) * d.x -
-                     (cz * d.y) * e1x - dz_e1y * cx;
-    if (Dok) {
-        const bool negB = (__float_as_int(db) ^ sD) < 0;
-        if (negB && fabsf(db) >= tiny) return false; // b < 0
-        if (!negB && (__float_as_int(da) ^ sD) >= 0 && fabsf(da + db) > aDm) return false; // a + b > 1
-    }
-    if (D == 0.0f) { // Matrix33.h:132-134: solve() returns (0,0,0); t = -0.0f
-        a = 0.0f;
-        b = 0.0f;
-        t = -0.0f;
-    } else {
-        float q;
-        div3_rn(da, db, dt, D, a, b, q);
-        t = -q;
-    }
-    return !(a < 0.0f || b < 0.0f || a + b > 1.0f || t < 0.0f || t > minT);
-}
-
 // The reference's test with nothing in front of it: the four determinants in its operation order, the three
-// quotients, its five comparisons.  For the frame walks, whose plane heads (below) have already dropped the
-// tests tri_test_cell's first stage was written for: what reaches the exact test there is a wave of which half the
-// lanes hold a triangle whose plane the ray crosses inside the current cell, most such waves hold a real hit,
-// and a stage that any lane needs is run by the wave - the staged early returns then only add their
+// quotients, its five comparisons.  This is the exact test of the frame walks, where two filters stand before
+// it (the plane heads and the edge records below): what reaches it is a wave of rays most of which hit, and a
+// stage that any lane needs is run by the whole wave, so tri_test's early returns would only add their
 // comparisons and the bookkeeping of who is still in (66 of 162 vector instructions).
+// How the walks' test got here (final.obj, 4K MSAA4, 1.44 G tests per frame): the walk knows which stretch
+// [lo, hi] of the ray lies in the cell it is in, and every cell lists every triangle that reaches into it, so a
+// triangle whose plane the ray crosses before lo has been tested in an earlier cell, one crossed after hi will
+// be met in a later one unless a nearer hit ends the walk first, one crossed behind the origin is no hit: 33 %
+// of the tests cross behind the origin, 15 % before the cell, 27 % beyond it, 6 % beyond the closest hit so
+// far, 19-25 % inside the cell.  First D and the numerator of t went to the front of the exact evaluation
+// (8.21 -> 8.07 ms per frame), then the plane head took their place at a third of the instructions (7.67 ms),
+// then the edge records dropped the three in four of the remaining tests whose wave holds no hit (7.30 ms).
 __device__ __forceinline__ bool tri_test_line(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d,
                                               float minT, float& a, float& b, float& t)
 {
@@ -349,9 +296,9 @@ __device__ __forceinline__ bool tri_test_line(const float4 q0, const float4 q1, 
 
 // The plane head of a slot, and what it decides.  With n = e1 x e2, the determinant of the reference's test is
 // D = n . dir and the numerator of t is N = n . (o - v2), t = -(N / D): where the ray crosses the triangle's
-// plane.  A walk that knows the stretch [lo, hi] of the ray inside its cell (tri_test_cell) drops four tests in
-// five on D and N alone - and evaluates both in the reference's operation order to do so, 45 instructions.
-// That decision only has to be safe, not bit-exact: the head holds (n, n . v2) divided by
+// plane.  A walk that knows the stretch [lo, hi] of the ray inside its cell can drop three tests in four on D
+// and N alone - in the reference's operation order that takes 45 instructions, but the decision only has to
+// be safe, not bit-exact: the head holds (n, n . v2) divided by
 // B = max_i (|e1_j e2_k| + |e1_k e2_j|), so that every component of the scaled normal, and of the sum of
 // absolute products behind it, is at most 1.  Then
 //   |D_ref / B - Dh| <= 11 * 2^-24 * (|dx| + |dy| + |dz|)            (7 roundings of the reference's sum of
@@ -359,7 +306,7 @@ __device__ __forceinline__ bool tri_test_line(const float4 q0, const float4 q1, 
 // with V >= |v2x| + |v2y| + |v2z|: two numbers per ray (tri_head_bounds: eD = 2^-20 * ..., eN = 2^-19 * ...,
 // neither below 2^-60, so that what is called certain stays clear of underflow in the reference's quotient
 // with B in [2^-40, 2^40]), no per-test error arithmetic.  The test is dropped only if t < 0, t > hi or t < lo holds for every (D, N) within those bounds
-// and the sign of D is certain; anything else goes on to tri_test_cell unchanged, so hits and their a, b, t
+// and the sign of D is certain; anything else goes on (to the edge record, then to tri_test_line), so hits and their a, b, t
 // stay the reference's bits.  A degenerate triangle (B = 0 or not finite) has a zero head: never dropped.
 __device__ __forceinline__ void tri_head_bounds(f3 o, f3 d, float vert_l1, float& eD, float& eN)
 {

@@ -220,36 +220,37 @@ __device__ __forceinline__ void wf_stk_top2(const WfStack& k, int sp, uint2& top
 // array.  Inner nodes carry no triangles (they were handed down to the leaves).  The
 // traversal arithmetic (plane distances) is free to use fused multiply-add: it only
 // decides which cells are visited, with a safety margin; which triangle is hit, and where,
-// is decided by tri_test alone.  The result equals the reference's leaf walk
+// is decided by the exact test (tri_test_line) alone.  The result equals the reference's leaf walk
 // (raytracing.cpp:281-351): the smallest t over all triangles, ties to the triangle that
 // walk would have tested last.  COUNT = false leaves the per-node and per-test statistics
 // out of the loops (two VALU instructions per step that only RtStats reads).
+// A leaf's triangles pass three stages, each fetched only for what the one before let through (final.obj
+// 4K MSAA4, per frame): the plane heads, two at a time (1.63 G tests, 18 M wave trips); the edge record of
+// the quarter whose plane the ray crosses inside the cell (12 M wave trips); the exact test for what is left
+// (2.7 M wave trips, nearly all with a hit).  A 16-byte plane record in front of an exact test that already
+// returned early was tried before the heads existed and lost to its own load (12.6 vs 12.05 ms); it pays
+// once it replaces the first part of the slot instead of preceding it.
 // Tried and not kept: fetching the node through the scalar cache while all lanes of a wave
 // sit at the same node (13.0 vs 12.0 ms per 4K frame: the uniformity test and the wait for
 // the scalar load cost more than the per-lane axis selects they save); skipping the re-test
 // of the triangle that already is the closest hit (3.5 % of the tests, no gain).
-// A plane filter in front of the exact test - three tests in four concern a triangle whose
-// plane the ray crosses outside the current cell, and such a crossing can be skipped with a
-// 16-byte plane record and ~20 instructions - removed 78 % of the exact tests (11.2 -> 2.5 per
-// ray) with all results unchanged, and made the frame slower (12.6 vs 12.05 ms): the extra
-// load per test costs more than the arithmetic it saves, and a large triangle no longer sets
-// the closest hit early from a distant cell (6 % more node steps).
-// Lanes at work (a -DWF_DIAG build counts them): 94 % in the node loop, 69 % in the triangle loop - a
+// Lanes at work (a -DWF_DIAG build counts them): 94-99 % in the node loop, 69-75 % in the triangle loop - a
 // wave tests as long as its fullest leaf.  Stepping over empty leaves inside the node loop (pop
 // and descend again without leaving it) raised the triangle loop to 77 % and cut its trips by
 // a tenth, but the heavier loop body ran 30 % more trips at 72 %: 11.1 vs 9.4 ms.
 // A box around each leaf's triangles, tested against the part of the ray inside the leaf's cell
 // before the triangles are: skips 47 % of the visits to leaves with triangles and 30 % of the
 // tests (11.2 -> 7.8 per ray), all results unchanged - and the frame takes 9.2-9.4 ms as before: the
-// tests it saves are the ones that end after the first numerator pair, and the box is one more
-// dependent load per leaf.
+// tests it saves are the cheapest ones, and the box is one more dependent load per leaf.
+// The exact test without its early returns directly behind the plane heads (no edge records): 7.70 vs 7.46 ms.
 #ifdef WF_DIAG
 // Diagnostic builds only (-DWF_DIAG): lane slots (wave trips x 64) of the node loop and of the triangle
 // loop of the counted launch; rt_api.hip prints them against the lanes that did work (final.obj 4K MSAA4:
 // 94 % in the node loop, 69 % in the triangle loop).
 __device__ unsigned long long g_diag[16]; // [4..7]: shadow rays traced / occluded, their triangle tests / node steps;
-                                         // [8] wave trips of the triangle loop in which a lane passes the plane head, [9] such lanes,
-                                         // [10] leaf visits by waves (trips of the outer loop), [11] lanes entering a leaf with triangles
+                                         // [8] wave trips (per head) in which a lane passes the plane head, [9] such lanes,
+                                         // [10] visits of leaves with triangles by waves, [11] trips of the triangle loop they make,
+                                         // [12] wave trips of the exact test with a hit, [13] such lanes, [14] wave trips past the edge records, [15] such lanes
 #endif
 #ifdef WF_SECT
 // Diagnostic builds only (-DWF_SECT): core-clock cycles the waves of the counted launch spend in each part of a
@@ -325,7 +326,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #ifdef WF_DIAG
         if (COUNT) {
             atomicAdd(&g_diag[cnt == 0 ? 2 : 3], 1ull);
-            int mx_ = cnt; // the longest list among the wave's lanes: the trips of the triangle loop; in pairs it would be half
+            int mx_ = cnt; // the longest list among the wave's lanes: two triangles per trip of the loop
             for (int d_ = 32; d_ > 0; d_ >>= 1) mx_ = max(mx_, __shfl_xor(mx_, d_));
             const unsigned long long a_ = __ballot(1);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1 && mx_ > 0)
@@ -1183,11 +1184,10 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     const int par = kind == WF_ST_CENTRE ? 1 : (level & 1); // centre 1, camera 0, level l: l & 1
     if (threadIdx.x == 0) sh->batch[par ^ 1] = 0;             // the stage after this one counts from 0
     const WfRays in = wf_ld(A->B.rays[level & 1]), out = wf_ld(A->B.rays[(level + 1) & 1]);
-#ifdef WF_BATCH_ALWAYS
-    const int bw = WF_BATCH_ALWAYS;
-#else
+    // (batches of 32 or 16 rays, to shorten the stages of the last regions of a launch: the stages of those regions
+    // take as long as before - it is the longest walk that counts, not how many lanes walk - and 1080p frames
+    // take 2.6 and 3.9 ms instead of 2.0)
     const int bw = 64;
-#endif
     const int    seg_c = (n_first + bw - 1) & ~(bw - 1);
     const int    total = seg_c + n_sh;
     const int    lane = threadIdx.x & 63;
