@@ -177,6 +177,113 @@ def test_degenerate_and_extreme_triangles(oracle, tmp_path):
         assert np.array_equal(g[hit].view(np.uint32), r[hit].view(np.uint32))
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e3])
+def test_filters_of_the_frame_walk_on_fine_and_coarse_meshes(oracle, scale):
+    """The frame walks put two filters before the exact ray/triangle test: the plane heads (where does the ray
+    cross the triangle's plane) and the edge records (on which side of its edges), both in fused arithmetic with
+    error bounds scaled by the ray and the scene.  A filter that drops a test the reference passes loses a hit.
+    Here nearly every ray runs along edges: a wavy sheet of 2 x 80 x 80 small triangles over two huge ones,
+    seen at a grazing angle and from above, the whole scene scaled by 1e-3, 1 and 1e3.  Pixel-centre triangle
+    and depth of the frame against (1) the library's per-ray entry point on the same rays - an exact closest-hit
+    search with neither filter, every pixel, bit for bit - and (2) the oracle's frame where the scene has the
+    size the reference was written for: its walk steps from leaf to leaf with absolute epsilons
+    (KDtree.cpp:288-587), mis-steps on a few rays per 100 000 at scale 1 and on one in twenty at scale 1000,
+    where a brute-force search over all triangles in double agrees with the GPU on every pixel the two differ on."""
+    n = 80
+    u, v = np.meshgrid(np.linspace(-2, 2, n + 1), np.linspace(-2, 2, n + 1), indexing="ij")
+    z = 0.15 * np.sin(3 * u) * np.cos(2 * v)
+    sheet = np.stack([u, v, z], axis=-1).reshape(-1, 3)
+    idx = lambda i, j: i * (n + 1) + j
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            tris.append((idx(i, j), idx(i + 1, j), idx(i, j + 1)))
+            tris.append((idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    base = len(sheet)
+    floor = np.float64([[-400, -400, -1], [400, -400, -1], [400, 400, -1], [-400, 400, -1]])
+    vpos = (np.concatenate([sheet, floor]) * scale).astype(np.float32)
+    tri_v = np.int32(tris + [(base, base + 1, base + 2), (base, base + 2, base + 3)])
+    mats = np.zeros((1, 16), np.float32)
+    mats[0, :10] = [0.7, 0.7, 0.7, 0.2, 0.2, 0.2, 10, 1.0, 2, 1]
+    s = oracle.Scene.from_arrays(vpos, tri_v, np.zeros(len(tri_v), np.int32), mats)
+    lights = np.float32([[1, 2, 5]]) * np.float32(scale)
+    s.set_lights(lights)
+    gs = gpu_scene_from_oracle(s)
+    W, H = 300, 200
+    for eye, up in (((0.0, -6.0, 0.4), (0, 0, 1)), ((0.3, 0.2, 7.0), (0, 1, 0))):     # grazing, from above
+        e = np.float64(eye) * scale
+        f = -e / np.linalg.norm(e)
+        r = np.cross(f, np.float64(up)); r /= np.linalg.norm(r)
+        w = np.cross(r, f)
+        # corner rays of a pinhole camera (RayTracer::raytrace blends them, main.cpp:514-526): origins at the
+        # eye, destinations on a plane 10 units (scaled) ahead; order (x, y) = (0, 0), (0, H - 1), (W - 1, 0), (W - 1, H - 1)
+        L, tx, ty = 10.0 * scale, 0.45, 0.30
+        corners = np.zeros(24, np.float32)
+        for k, (sx, sy) in enumerate(((-1, 1), (-1, -1), (1, 1), (1, -1))):
+            corners[6 * k:6 * k + 3] = e
+            corners[6 * k + 3:6 * k + 6] = e + L * (f + sx * tx * r + sy * ty * w)
+        grgb, gdepth, gtri, st = gs.render(corners, lights, pkg().capi.default_params(W, H, 1))
+        assert (gtri >= 0).mean() > 0.5
+        O, D = np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32)
+        for y in range(H):
+            for x in range(W):
+                O[y, x], D[y, x] = oracle.pixel_ray(corners, W, H, x, y)
+        ctri, _, _, ct, _ = gs.check_hits(O.reshape(-1, 3), D.reshape(-1, 3))
+        ctri, ct = ctri.reshape(H, W), ct.reshape(H, W)
+        assert np.array_equal(gtri, ctri), (scale, eye, (gtri != ctri).sum())
+        hit = ctri >= 0
+        assert np.array_equal(gdepth[hit].view(np.uint32), ct[hit].view(np.uint32))
+        assert (gdepth[~hit] == np.float32(3.402823466e+38)).all()
+        if scale <= 1.0:
+            frgb, fdepth, ftri = s.render(corners, W, H, threads=8)
+            same = gtri == ftri
+            assert same.mean() >= 0.9998, (scale, eye, (~same).sum())
+            assert np.array_equal(gdepth[same].view(np.uint32), fdepth[same].view(np.uint32))
+
+
+def test_hard_bright_highlights_through_the_frame_pipeline(oracle):
+    """The frame pipeline forms the specular power as 2^(n log2 x) with the hardware's log2 and exp2 and
+    normalises the view and halfway vectors with its reciprocal square root (rt_wavefront.h: wf_pow, wf_unit);
+    the reference calls std::pow on exactly normalised vectors (raytracing.cpp:131-134).  The relative error of
+    the power grows with the hardness n.  A wavy sheet with n = 1000 and a specular colour of 3 (brighter than
+    any of the reference's materials: highlights clip) under three lights, against the oracle: float colours
+    within 5e-4 of a colour unit (an eighth of a byte step), bytes within 1 LSB everywhere."""
+    n = 60
+    u, v = np.meshgrid(np.linspace(-2, 2, n + 1), np.linspace(-2, 2, n + 1), indexing="ij")
+    z = 0.25 * np.sin(2.5 * u) * np.cos(2 * v)
+    vpos = np.stack([u, v, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    idx = lambda i, j: i * (n + 1) + j
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            tris.append((idx(i, j), idx(i + 1, j), idx(i, j + 1)))
+            tris.append((idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    mats = np.zeros((1, 16), np.float32)
+    mats[0, :10] = [0.05, 0.05, 0.08, 3.0, 3.0, 3.0, 1000, 1.0, 2, 1]
+    s = oracle.Scene.from_arrays(vpos, np.int32(tris), np.zeros(len(tris), np.int32), mats)
+    lights = np.float32([[0.5, 0.5, 4], [-3, 1, 2], [2, -3, 3]])
+    s.set_lights(lights)
+    gs = gpu_scene_from_oracle(s)
+    W, H = 320, 240
+    e = np.float64([0.2, -2.5, 3.5])
+    f = -e / np.linalg.norm(e)
+    r = np.cross(f, np.float64([0, 0, 1])); r /= np.linalg.norm(r)
+    w = np.cross(r, f)
+    corners = np.zeros(24, np.float32)
+    for k, (sx, sy) in enumerate(((-1, 1), (-1, -1), (1, 1), (1, -1))):
+        corners[6 * k:6 * k + 3] = e
+        corners[6 * k + 3:6 * k + 6] = e + 10.0 * (f + sx * 0.5 * r + sy * 0.375 * w)
+    frgb, fdepth, ftri = s.render(corners, W, H, threads=8)
+    grgb, gdepth, gtri, st = gs.render(corners, lights, pkg().capi.default_params(W, H, 1))
+    same = (gtri == ftri) & (ftri >= 0)
+    assert same.mean() > 0.5
+    lit = same & (frgb.max(axis=2) > 0.2)            # pixels inside a highlight
+    assert lit.sum() > 500
+    assert np.abs(grgb[same] - frgb[same]).max() < 5e-4
+    d = np.abs(oracle.to_bytes(grgb[same]).astype(int) - oracle.to_bytes(frgb[same]).astype(int))
+    assert d.max() <= 1
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_random_scenes_match_oracle(oracle, seed):
     """Scenes no fixture knows: a few hundred random triangles (a soup: they intersect each
