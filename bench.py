@@ -729,7 +729,11 @@ def main():
                         "so the ceiling is the FP32 rate, which is the same 157.3 TFLOP/s for vector FMA "
                         "and dense f32 MFMA", "kernel": "k_wf_pipeline", "achieved": round(ach, 3),
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
-                        "traffic": traffic, "kernel_ms": round(kern_ms, 3),
+                        "traffic": traffic,
+                        "traffic_is": "bytes between the L2s and the memory side of the fabric per launch (FETCH_SIZE doubled "
+                                      "per the gfx950 correction + WRITE_SIZE, profiles/traffic.json): Infinity-Cache hits are "
+                                      "counted in it, no counter of this stack separates them - an upper bound of the HBM bytes",
+                        "kernel_ms": round(kern_ms, 3),
                         "launches_per_frame": round(kt.frames / args.steps, 2),
                         "frames_in_flight": n_flight,
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),

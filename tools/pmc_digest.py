@@ -1,7 +1,7 @@
 """Digest of the PMC passes tools/profile_round.sh leaves in a directory: per launch of the
 timed pipeline kernel (k_wf_pipeline<false, false>), counters averaged over its launches, plus
-the derived figures the design notes quote (lanes active, VALU busy, HBM traffic with the gfx950
-correction of the FETCH_SIZE counter, cache hit rates)."""
+the derived figures the design notes quote (lanes active, VALU busy, the bytes between L2 and the memory
+side of the fabric with the gfx950 correction of the FETCH_SIZE counter, cache hit rates)."""
 import csv, glob, json, os, sys
 d = sys.argv[1]
 vals = {}
@@ -22,8 +22,19 @@ if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
     out["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0), 4)
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     rd, wr = g("FETCH_SIZE") * 1024.0, g("WRITE_SIZE") * 1024.0
-    out["hbm_bytes_per_launch"] = {"read_raw": rd, "read_corrected_x2": 2 * rd, "write": wr, "total_corrected": 2 * rd + wr,
-                                   "correction": "gfx950: FETCH_SIZE tallies 128-B requests as 64 B; read side doubled, WRITE_SIZE exact"}
+    out["fabric_bytes_per_launch"] = {"read_raw": rd, "read_corrected_x2": 2 * rd, "write": wr, "total_corrected": 2 * rd + wr,
+                                   "correction": "gfx950: FETCH_SIZE tallies 128-B requests as 64 B; read side doubled, WRITE_SIZE exact",
+                                   "what": "bytes between the L2s and the memory side of the fabric (Infinity Cache + HBM); an upper bound of the HBM bytes"}
+if g("TCC_EA0_RDREQ_sum") and g("TCC_EA0_WRREQ_sum"):
+    # Where the L2's misses go.  *_DRAM counts the requests addressed to the local memory controllers (as opposed to
+    # another device or the host); the Infinity Cache sits in front of those controllers, on the memory side of the
+    # fabric, so a request it serves is counted here like one that reaches HBM: these counters bound the HBM bytes
+    # from above and cannot say how far above.
+    out["l2_to_memory_requests"] = {
+        "read": g("TCC_EA0_RDREQ_sum"), "read_for_dram": g("TCC_EA0_RDREQ_DRAM_sum"),
+        "write": g("TCC_EA0_WRREQ_sum"), "write_for_dram": g("TCC_EA0_WRREQ_DRAM_sum"),
+        "what": "every read and write request the L2 sends on is addressed to local memory (none to a peer or the host); "
+                "Infinity-Cache hits are among them - no counter of this stack separates them from HBM accesses"}
 if g("TCC_HIT_sum") and g("TCC_REQ_sum"):
     out["l2_hit_rate"] = round(g("TCC_HIT_sum") / g("TCC_REQ_sum"), 4)
 if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum"):

@@ -17,13 +17,16 @@ for f in sorted(os.listdir(src)):
 dig = json.load(open(os.path.join(src, "digest.json")))
 tr_path = os.path.join(dst, "traffic.json")
 tr = json.load(open(tr_path))
-h = dig["hbm_bytes_per_launch"]
+h = dig.get("fabric_bytes_per_launch") or dig["hbm_bytes_per_launch"]
 hist = tr.setdefault("history", {})
 hist[tag] = {"read_raw": h["read_raw"], "write": h["write"], "total_corrected": h["total_corrected"]}
 tr["kernel"] = f"k_wf_pipeline<false, false>, final.obj 3840x2160 MSAA4, one launch = one frame (profiles/{tag}_pmc_fetch.csv, {tag}_pmc_write.csv)"
 tr["FETCH_SIZE_KB_per_launch_raw"] = dig["counters"]["FETCH_SIZE"]
 tr["WRITE_SIZE_KB_per_launch_raw"] = dig["counters"]["WRITE_SIZE"]
 tr["k_wf_pipeline_hbm_bytes_per_launch"] = int(h["total_corrected"])
+tr["k_wf_pipeline_fabric_bytes_per_launch"] = int(h["total_corrected"])
+if dig.get("l2_to_memory_requests"):
+    tr["l2_to_memory_requests_per_launch"] = dig["l2_to_memory_requests"]
 tr["k_wf_pipeline_hbm_bytes_per_launch_uncorrected"] = int(h["read_raw"] + h["write"])
 json.dump(tr, open(tr_path, "w"), indent=1)
 print("saved", tag, int(h["total_corrected"]))
