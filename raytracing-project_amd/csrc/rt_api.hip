@@ -1411,7 +1411,7 @@ static void read_stats(RtScene* s, RtStats* st, hipStream_t stream)
                 (double)c.tri_tests / (double)(d[1] ? d[1] : 1), (unsigned long long)c.tri_tests, d[1]);
         fprintf(stderr, "diag: leaf visits: %llu empty, %llu with triangles\n", d[2], d[3]);
         fprintf(stderr, "diag: triangle loop: %llu wave trips, %llu with a lane past the plane head (%.3f), %llu such lanes (%.3f of the tests)\n",
-                d[1] / 64, d[8], (double)d[8] / (double)(d[1] ? d[1] / 64 : 1), d[9], (double)d[9] / (double)(c.tri_tests ? c.tri_tests : 1));
+                d[1] / 128, d[8], (double)d[8] / (double)(d[1] ? d[1] / 64 : 1), d[9], (double)d[9] / (double)(c.tri_tests ? c.tri_tests : 1));
         fprintf(stderr, "diag: exact tests: %llu wave trips with a lane that hits (%.3f of the trips past the head), %llu such lanes (%.3f of the lanes past the head)\n",
                 d[12], (double)d[12] / (double)(d[8] ? d[8] : 1), d[13], (double)d[13] / (double)(d[9] ? d[9] : 1));
         fprintf(stderr, "diag: edge records: %llu wave trips with a lane past them (%.3f of the trips past the head), %llu such lanes\n",

@@ -292,6 +292,9 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
     for (;;) {
         uint2 nd = S.knodes[node];
         if (COUNT) ++n_nodes;
+#ifdef WF_DIAG
+        if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
+#endif
         while ((nd.y >> 30) != 3u) {
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
@@ -342,7 +345,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             const bool two = i + 1 < cnt;
             if (COUNT) n_tests += two ? 2u : 1u;
 #ifdef WF_DIAG
-            if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 64ull); }
+            if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[1], 128ull); }
 #endif
             // (the heads as two 16-byte loads, complete here: the compiler would otherwise fetch words of them
             // later, behind a wait for a whole slot)
