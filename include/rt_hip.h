@@ -163,6 +163,16 @@ void rt_default_params(RtParams *p, int32_t width, int32_t height);
 int         rt_device_count(void);
 const char *rt_last_error(void);
 
+/* buildKDtree (KDtree.cpp:15-230: splitSpaces and the 999-candidate scan of calcBestSplit) on the device:
+ * the tree the reference builds for these triangles, node for node - bounds, children, the triangles every
+ * node keeps and their order - numbered as the reference's recursion creates nodes (children when their
+ * parent is expanded, left subtree first).  nodes: room for max_nodes (4 * n_triangles + 64 always
+ * suffices); node_tris: room for n_triangles; depth: the deepest node (may be null).  What comes out is what
+ * RtSceneDesc.nodes / node_tris take. */
+int  rt_build_kd_tree(int device, int32_t n_vertices, const float *vertex_pos, int32_t n_triangles,
+                      const int32_t *tri_vertex, int32_t max_nodes, RtKdNode *nodes, int32_t *n_nodes,
+                      int32_t *node_tris, int32_t *depth);
+
 /* Takes over from the end of init() (raytracing.cpp:23-53): the mesh is
  * loaded, normals computed, the KD tree built; this call lays both out for
  * the GPU and uploads them to `device`.  The host arrays are not referenced

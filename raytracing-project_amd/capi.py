@@ -86,7 +86,7 @@ EXPORTS = [
     "rt_postprocess_device", "rt_quantize", "rt_tile_pixels", "rt_pack_tiles_device", "rt_unpack_tiles_device",
     "rt_rccl_unique_id", "rt_rccl_comm_create", "rt_rccl_comm_destroy", "rt_gather_tiles_rccl",
     "rt_render_result_planes_shared", "rt_render_result_planes_rehearsal", "rt_deal_params", "rt_scene_set_deal", "rt_scene_set_region_order",
-    "rt_calibrate_deal",
+    "rt_calibrate_deal", "rt_build_kd_tree",
 ]
 
 _lib = None
@@ -148,6 +148,7 @@ def lib():
     L.rt_scene_set_deal.argtypes = [P, I32]
     L.rt_scene_set_region_order.argtypes = [P, I32]
     L.rt_calibrate_deal.argtypes = [P, P, I32, I32, P, P, I32, C.POINTER(RtParams), C.POINTER(I32)]
+    L.rt_build_kd_tree.argtypes = [C.c_int, I32, P, I32, P, I32, P, C.POINTER(I32), P, C.POINTER(I32)]
     L.rt_rccl_unique_id.argtypes = [P]
     L.rt_rccl_comm_create.argtypes = [P, I32, I32, C.c_int, C.POINTER(P)]
     L.rt_rccl_comm_destroy.argtypes = [P]
@@ -334,6 +335,26 @@ class Scene:
                                            C.c_void_p(d_tri) if d_tri else None,
                                            C.c_void_p(stream), C.byref(st) if stats else None))
         return st
+
+
+def build_kd_tree(vertex_pos, tri_vertex, device=0):
+    """rt_build_kd_tree: the reference's KD tree for these triangles, built on the GPU.  Returns a dict of
+    arrays in node order: bounds (n, 6), left, right, tri_off, tri_cnt, tris, and depth."""
+    vp = _f32(vertex_pos).reshape(-1, 3)
+    tv = np.ascontiguousarray(tri_vertex, np.int32).reshape(-1, 3)
+    nt = len(tv)
+    cap = 4 * nt + 64
+    nodes = (RtKdNode * cap)()
+    n_nodes, depth = C.c_int32(0), C.c_int32(0)
+    tris = np.zeros(max(nt, 1), np.int32)
+    check(lib().rt_build_kd_tree(device, len(vp), _ptr(vp), nt, tv.ctypes.data_as(C.c_void_p), cap,
+                                 C.cast(nodes, C.c_void_p), C.byref(n_nodes), tris.ctypes.data_as(C.c_void_p),
+                                 C.byref(depth)))
+    n = n_nodes.value
+    raw = np.frombuffer(nodes, dtype=np.dtype([("bounds", np.float32, 6), ("left", np.int32), ("right", np.int32),
+                                               ("tri_off", np.int32), ("tri_cnt", np.int32)]), count=n)
+    return {"bounds": raw["bounds"].copy(), "left": raw["left"].copy(), "right": raw["right"].copy(),
+            "tri_off": raw["tri_off"].copy(), "tri_cnt": raw["tri_cnt"].copy(), "tris": tris[:nt], "depth": depth.value}
 
 
 def normalize_depth(depth, focus=0.0, device=0):

@@ -17,6 +17,8 @@
 // coordinate per triangle) instead of re-classifying every triangle per plane.
 #include <algorithm>
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 
 #include "rt_host.hpp"
 
@@ -68,6 +70,24 @@ void buildKDtree(const Mesh& mesh, KdTree& tree)
     tree = KdTree();
     const size_t nt = mesh.triangleCount();
     if (nt == 0) return;
+    // RT_KD_BUILD_GPU=1: the same tree from the device (rt_build_kd_tree: one block per node of a level, the
+    // 999 candidate planes of a node spread over its threads).  The loops below stay the default: the
+    // reference's trees take them a few milliseconds, and a test holds the two against each other.
+    if (const char* e = std::getenv("RT_KD_BUILD_GPU"); e && e[0] == '1') {
+        const int32_t cap = 4 * (int32_t)nt + 64;
+        tree.nodes.resize((size_t)cap);
+        tree.node_tris.resize(nt);
+        int32_t n_nodes = 0, depth = 0;
+        const int rc = rt_build_kd_tree(0, (int32_t)(mesh.positions.size() / 3), mesh.positions.data(), (int32_t)nt,
+                                        mesh.tri_vertex.data(), cap, tree.nodes.data(), &n_nodes, tree.node_tris.data(), &depth);
+        if (rc == RT_OK) {
+            tree.nodes.resize((size_t)n_nodes);
+            tree.depth = depth;
+            return;
+        }
+        std::fprintf(stderr, "buildKDtree: RT_KD_BUILD_GPU=1, but %s - building on the host\n", rt_last_error());
+        tree = KdTree();
+    }
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) lo[a] = hi[a] = mesh.positions[3 * mesh.tri_vertex[0] + a];
     for (size_t t = 0; t < nt; ++t)

@@ -18,6 +18,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_device.h"
 #include "rt_kdrefine.h"
+#include "rt_kdbuild.h"
 
 #pragma clang fp contract(off)
 
@@ -1989,6 +1990,113 @@ static int check_device(int device)
     if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
     if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device %d out of range", device);
     HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the reference's KD tree, built on the device (rt_kdbuild.h)
+// ---------------------------------------------------------------------------
+extern "C" int rt_build_kd_tree(int device, int32_t n_vertices, const float* vertex_pos, int32_t n_triangles,
+                                const int32_t* tri_vertex, int32_t max_nodes, RtKdNode* nodes_out, int32_t* n_nodes_out,
+                                int32_t* node_tris_out, int32_t* depth_out)
+{
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (!vertex_pos || !tri_vertex || !nodes_out || !n_nodes_out || !node_tris_out || n_vertices < 1 || n_triangles < 1 ||
+        max_nodes < 1)
+        return fail(RT_ERR_INVALID, "rt_build_kd_tree: null or empty argument");
+    const int nt = n_triangles;
+    for (int i = 0; i < 3 * nt; ++i)
+        if (tri_vertex[i] < 0 || tri_vertex[i] >= n_vertices)
+            return fail(RT_ERR_INVALID, "rt_build_kd_tree: triangle %d names vertex %d of %d", i / 3, tri_vertex[i], n_vertices);
+    // root box, KDtree.cpp:15-60: the bounds of the vertices the triangles use, grown by 5.1
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = vertex_pos[3 * tri_vertex[0] + a];
+    for (int i = 0; i < 3 * nt; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float c = vertex_pos[3 * tri_vertex[i] + a];
+            if (c < lo[a]) lo[a] = c;
+            else if (c > hi[a]) hi[a] = c;
+        }
+    const int cap_nodes = 4 * nt + 64, cap_items = 2 * (nt / 11) + 16;
+    DevBuf    d_pos, d_tv, d_list[2], d_kept, d_nodes, d_items[2], d_ctl;
+    if ((rc = d_pos.alloc(sizeof(float) * 3 * (size_t)n_vertices)) || (rc = d_tv.alloc(sizeof(int32_t) * 3 * (size_t)nt)) ||
+        (rc = d_list[0].alloc(sizeof(int32_t) * (size_t)nt)) || (rc = d_list[1].alloc(sizeof(int32_t) * (size_t)nt)) ||
+        (rc = d_kept.alloc(sizeof(int32_t) * (size_t)nt)) || (rc = d_nodes.alloc(sizeof(KdbNode) * (size_t)cap_nodes)) ||
+        (rc = d_items[0].alloc(sizeof(KdbItem) * (size_t)cap_items)) || (rc = d_items[1].alloc(sizeof(KdbItem) * (size_t)cap_items)) ||
+        (rc = d_ctl.alloc(sizeof(KdbCtl))))
+        return rc;
+    HIP_TRY(hipMemcpy(d_pos.p, vertex_pos, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tv.p, tri_vertex, sizeof(int32_t) * 3 * (size_t)nt, hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> all((size_t)nt);
+        for (int t = 0; t < nt; ++t) all[(size_t)t] = t;
+        HIP_TRY(hipMemcpy(d_list[0].p, all.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
+        KdbNode root{};
+        for (int a = 0; a < 3; ++a) root.b[2 * a] = lo[a] - 5.1f, root.b[2 * a + 1] = hi[a] + 5.1f;
+        root.left = root.right = -1;
+        HIP_TRY(hipMemcpy(d_nodes.p, &root, sizeof root, hipMemcpyHostToDevice));
+        const KdbItem first{0, 0, 0, nt};
+        HIP_TRY(hipMemcpy(d_items[0].p, &first, sizeof first, hipMemcpyHostToDevice));
+        KdbCtl ctl{};
+        ctl.n_nodes = 1;
+        HIP_TRY(hipMemcpy(d_ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice));
+    }
+    int n_items = 1, kept_used = 0, n_nodes = 1;
+    for (int level = 0; n_items > 0; ++level) {
+        if (level > 63) return fail(RT_ERR_UNSUPPORTED, "rt_build_kd_tree: the tree is deeper than 63 levels");
+        const int cur = level & 1;
+        hipLaunchKernelGGL(k_kd_build_level, dim3((unsigned)n_items), dim3(KDB_BLOCK), 0, 0, (const float*)d_pos.p,
+                           (const int32_t*)d_tv.p, (const KdbItem*)d_items[cur].p, (const int32_t*)d_list[cur].p,
+                           (int32_t*)d_list[cur ^ 1].p, (int32_t*)d_kept.p, (KdbNode*)d_nodes.p, (KdbItem*)d_items[cur ^ 1].p,
+                           (KdbCtl*)d_ctl.p, cap_nodes, cap_items, nt);
+        HIP_TRY(hipGetLastError());
+        KdbCtl ctl;
+        HIP_TRY(hipMemcpy(&ctl, d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost)); // (waits for the level)
+        if (ctl.overflow) return fail(RT_ERR_UNSUPPORTED, "rt_build_kd_tree: more than %d nodes", cap_nodes);
+        n_items = ctl.n_next, n_nodes = ctl.n_nodes, kept_used = ctl.kept_used;
+        ctl.n_next = 0, ctl.list_used = 0;
+        HIP_TRY(hipMemcpy(d_ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice));
+    }
+    if (kept_used != nt) return fail(RT_ERR_HIP, "rt_build_kd_tree: %d of %d triangles placed", kept_used, nt);
+    if (n_nodes > max_nodes) return fail(RT_ERR_INVALID, "rt_build_kd_tree: %d nodes, room for %d", n_nodes, max_nodes);
+    std::vector<KdbNode> bn((size_t)n_nodes);
+    std::vector<int32_t> kept((size_t)nt);
+    HIP_TRY(hipMemcpy(bn.data(), d_nodes.p, sizeof(KdbNode) * (size_t)n_nodes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(kept.data(), d_kept.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+    // The reference's numbering: a node's children get the next two numbers when the node is expanded, and the
+    // left subtree is expanded before the right one (KDtree.cpp:75-130).
+    std::vector<int32_t> final_id((size_t)n_nodes, -1), order;
+    std::vector<int32_t> stack{0};
+    int32_t              next_id = 1, depth = 0;
+    final_id[0] = 0;
+    while (!stack.empty()) {
+        const int32_t b = stack.back();
+        stack.pop_back();
+        depth = std::max(depth, bn[(size_t)b].depth);
+        if (bn[(size_t)b].left >= 0) {
+            final_id[(size_t)bn[(size_t)b].left] = next_id, final_id[(size_t)bn[(size_t)b].right] = next_id + 1;
+            next_id += 2;
+            stack.push_back(bn[(size_t)b].right);
+            stack.push_back(bn[(size_t)b].left);
+        }
+    }
+    if (next_id != n_nodes) return fail(RT_ERR_HIP, "rt_build_kd_tree: %d of %d nodes reachable", next_id, n_nodes);
+    std::vector<int32_t> by_final((size_t)n_nodes);
+    for (int32_t b = 0; b < n_nodes; ++b) by_final[(size_t)final_id[(size_t)b]] = b;
+    int32_t off = 0;
+    for (int32_t f = 0; f < n_nodes; ++f) {
+        const KdbNode& k = bn[(size_t)by_final[(size_t)f]];
+        RtKdNode&      o = nodes_out[f];
+        for (int a = 0; a < 6; ++a) o.bounds[a] = k.b[a];
+        o.left = k.left >= 0 ? final_id[(size_t)k.left] : -1;
+        o.right = k.right >= 0 ? final_id[(size_t)k.right] : -1;
+        o.tri_offset = off, o.tri_count = k.kept_cnt;
+        for (int32_t i = 0; i < k.kept_cnt; ++i) node_tris_out[off + i] = kept[(size_t)(k.kept_off + i)];
+        off += k.kept_cnt;
+    }
+    *n_nodes_out = n_nodes;
+    if (depth_out) *depth_out = depth;
     return RT_OK;
 }
 

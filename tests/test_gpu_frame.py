@@ -89,6 +89,45 @@ def test_tree_built_on_the_gpu_equals_the_host_built_one(P, monkeypatch, name):
               f"{h['tree_ms']:.1f} ms on the host; rt_scene_create {g['create_ms']:.1f} / {h['create_ms']:.1f} ms")
 
 
+@pytest.mark.parametrize("name", ["ball", "redballs", "refractionballs", "lego", "final", "fin", "checkercube"])
+def test_reference_tree_built_on_the_gpu(P, monkeypatch, name):
+    """rt_build_kd_tree: buildKDtree / splitSpaces / calcBestSplit (KDtree.cpp:15-230) on the device.  The tree
+    must be (1) the one the real reference built for the scene - bounds, leaves, the triangles every node
+    keeps and their order, in the preorder the reference was dumped in (tests/golden/<scene>.npz, for the five
+    scenes that have a fixture) - and (2) the one the host loops build, node for node, also when the C++ host
+    is told to take its tree from the device (RT_KD_BUILD_GPU=1)."""
+    monkeypatch.delenv("RT_KD_BUILD_GPU", raising=False)
+    hs = P.host.HostScene(os.path.join(SCENES, name + ".obj"))
+    a = hs.arrays()
+    t = P.capi.build_kd_tree(a["vertex_pos"], a["tri_vertex"])
+    assert t["depth"] == a["tree_depth"]
+    for mine, host in (("bounds", "node_bounds"), ("left", "node_left"), ("right", "node_right"),
+                       ("tri_off", "node_tri_off"), ("tri_cnt", "node_tri_cnt"), ("tris", "node_tris")):
+        assert np.array_equal(t[mine].view(np.uint32) if mine == "bounds" else t[mine],
+                              a[host].view(np.uint32) if mine == "bounds" else a[host]), (name, mine)
+    gold = os.path.join(os.path.dirname(__file__), "golden", name + ".npz")
+    if os.path.exists(gold):
+        g = np.load(gold)
+        order, stack = [], [0]
+        while stack:                                  # preorder, left first: the order of the reference's dump
+            n = stack.pop()
+            order.append(n)
+            if t["left"][n] >= 0:
+                stack += [t["right"][n], t["left"][n]]
+        order = np.array(order)
+        assert len(order) == len(g["ref_tree_leaf"])
+        assert np.array_equal(t["bounds"][order], g["ref_tree_bounds"])
+        assert np.array_equal((t["left"][order] < 0).astype(np.int32), g["ref_tree_leaf"])
+        assert np.array_equal(t["tri_cnt"][order], g["ref_tree_tri_cnt"])
+        mine = np.concatenate([t["tris"][t["tri_off"][n]:t["tri_off"][n] + t["tri_cnt"][n]] for n in order])
+        assert np.array_equal(mine, g["ref_tree_tris"])
+    monkeypatch.setenv("RT_KD_BUILD_GPU", "1")
+    b = P.host.HostScene(os.path.join(SCENES, name + ".obj")).arrays()
+    monkeypatch.delenv("RT_KD_BUILD_GPU")
+    for key in ("node_bounds", "node_left", "node_right", "node_tri_off", "node_tri_cnt", "node_tris", "tree_depth"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), (name, key)
+
+
 def test_normalize_depth_matches_oracle(P, oracle):
     rng = np.random.default_rng(2)
     d = (rng.random(100003, dtype=np.float32) * 0.9 + 0.05).astype(np.float32)
