@@ -1228,7 +1228,8 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                     valid = valid && idx < n_slots && slot_to_pixel(P, g.slot_base + idx, x, y);
                     xy = x | (y << 16);
                 }
-                if (valid) {
+                if (valid) { // (the four blend weights from a table per column and row instead of two double divisions per
+                             // ray: the same rays bit for bit and the same frame times - the divisions hide behind the walks)
                     double fx = (double)x, fy = (double)y;
                     if (sn >= 0) {
                         fx += (double)(msaa == 4 ? c_msaa4[sn][0] : c_msaa16[sn][0]);

@@ -249,6 +249,9 @@ def test_library_deal_covers_every_pixel_once(P, W, H, n_ranks, first):
     for bad in ((0, first, 0), (n_ranks, 0, 0), (n_ranks, 17, 0), (n_ranks, first, n_ranks), (n_ranks, first, -1)):
         assert L.rt_deal_params(C.byref(frame), bad[0], bad[1], bad[2], C.byref(p)) == -1
     assert L.rt_scene_set_deal(None, 8) == -1
+    assert L.rt_scene_set_region_order(None, 1) == -1
+    # (without a GPU every device call ends at the device check; with one, at the argument check)
+    assert L.rt_build_kd_tree(0, 0, None, 0, None, 0, None, None, None, None) < 0
 
 
 def test_tile_pack_unpack_roundtrip(P):
