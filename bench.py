@@ -682,6 +682,9 @@ def main():
                         % (other_flight, "s" if other_flight > 1 else "",
                            "throughput of consecutive frames, the launch of frame i + 1 fills the GPU as the last "
                            "regions of frame i run out" if other_flight == 2 else "the time of one frame", n_flight)},
+            "region_order": "every launch of the timed loop starts the regions it would otherwise wait for first, from the "
+                            "durations the frame before left in the scene (rt_scene_set_region_order, the library's default); "
+                            "nothing of a frame's result is carried over - every ray of every frame is traced",
             "regions_by_index": by_index,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "data": "scenes/final.obj + scenes/cameras/final.sav (the reference's own scene; no "
