@@ -627,6 +627,21 @@ def test_region_order_from_the_last_frame_changes_nothing(P, monkeypatch):
             assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
             assert np.array_equal(got[2], want[2])
             assert got[3].rays_closest == want[3].rays_closest and got[3].rays_shadow == want[3].rays_shadow
+        # the order is a permutation of the regions: a frame rendered into planes full of NaN leaves none
+        # behind in the pixels this rank owns and equals the plain frame there
+        import torch
+        rgb = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        depth = torch.full((H, W), float("nan"), dtype=torch.float32, device="cuda")
+        gs.render_device(corners, lights, p, rgb.data_ptr(), depth.data_ptr(), 0, 0, False)
+        torch.cuda.synchronize()
+        plain_rgb = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        plain_depth = torch.full((H, W), float("nan"), dtype=torch.float32, device="cuda")
+        plain.render_device(corners, lights, p, plain_rgb.data_ptr(), plain_depth.data_ptr(), 0, 0, False)
+        torch.cuda.synchronize()
+        assert torch.equal(rgb.view(torch.int32), plain_rgb.view(torch.int32))
+        assert torch.equal(depth.view(torch.int32), plain_depth.view(torch.int32))
+        if world == 1:
+            assert not bool(torch.isnan(depth).any())
 
 
 def test_chunked_frame_and_many_lights(P, monkeypatch):
