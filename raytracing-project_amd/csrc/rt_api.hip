@@ -1146,13 +1146,14 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         heads[p2] = make_float4(a.x, b.x, a.y, b.y);
         heads[p2 + 1] = make_float4(a.z, b.z, a.w, b.w);
     }
+    if (nodes.size() >= (1u << 27)) return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many tree nodes");
     std::vector<uint2> knodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); ++k) {
         const DNode& n = nodes[k];
         if (n.left >= 0) {
             unsigned bits;
             memcpy(&bits, &n.split, 4);
-            knodes[k] = make_uint2(bits, ((unsigned)(n.cnt_axis >> 28) << 30) | (unsigned)n.left);
+            knodes[k] = make_uint2(bits, ((unsigned)(n.cnt_axis >> 28) << 30) | ((unsigned)n.left * 8u)); // (the left child's record, in bytes)
         } else {
             knodes[k] = make_uint2((unsigned)n.tri_off, (3u << 30) | (unsigned)(n.cnt_axis & 0x0fffffff));
         }

@@ -92,6 +92,10 @@ __device__ __forceinline__ unsigned wf_meta(unsigned sample, unsigned k, unsigne
     return sample | (k << 16) | ((route & 0xffu) << 19);
 }
 
+// A shadow ray's tag (w of its queue entry): bits 0-22 the ray slot of its hit, 23 WF_TAG_SOLE, 24-31 the light.
+#define WF_TAG_SOLE 0x800000u
+#define WF_TAG_SLOT 0x7fffffu
+
 // Record of a hit that waits for shadow answers; `rec_stride` bytes apart.  After it: per light
 // the value the light's angle sets shadowMax to before its query (-1 = leaves it), then, with
 // soft shadows, per light the number of occluded samples (one byte each).
@@ -101,6 +105,8 @@ struct WfRecord {
     unsigned sample;     // of the region
     unsigned pending;    // bits 0-7 queries still out, 8-31 lights 0-23 found occluded; soft shadows: queries only
     unsigned occ_hi[2];  // lights 24-87 found occluded
+    // (a hit with a single query, hard shadows: `pending` and occ_hi[0] hold the sum of shadowMax over the lights
+    // with that query answered "free" and "occluded", as float bits - see WF_TAG_SOLE)
 };
 
 // Buffers that exist once per level parity lie back to back: parity 1 starts one stride
@@ -266,6 +272,14 @@ __device__ unsigned long long g_sect[16];
 #define WF_SC(i) do { } while (0)
 #define WF_SC_END do { } while (0)
 #endif
+// A node's record.  The walk names a node by where its record lies, in bytes from the first (what an inner
+// node stores for its left child, and what goes on the stack): the address is the array plus that word, with no
+// index arithmetic per step.
+__device__ __forceinline__ uint2 wf_node(const DScene& S, unsigned at)
+{
+    return *(const uint2*)((const char*)S.knodes + at);
+}
+
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
@@ -290,33 +304,33 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
     }
     const RayPairs rp = {v2f{o.x, o.y}, v2f{o.z, d.x}, v2f{d.y, d.z}};
     for (;;) {
-        uint2 nd = S.knodes[node];
+        uint2 nd = wf_node(S, (unsigned)node);
         if (COUNT) ++n_nodes;
 #ifdef WF_DIAG
         if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
 #endif
-        while ((nd.y >> 30) != 3u) {
+        while (nd.y < 0xc0000000u) { // axis 0..2 in bits 30-31, 3 = leaf
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
 #endif
-            const unsigned axis = nd.y >> 30;
-            const int      left = (int)(nd.y & 0x3fffffffu);
+            const int left = (int)(nd.y & 0x3fffffffu); // where the left child's record is, in bytes from the first
             // Both children lie side by side: their records are asked for before the plane decides which
             // one the walk takes, so the decision is made while the load is under way and the chain
             // from node to node is the load alone.
-            const uint2 c0 = S.knodes[left], c1 = S.knodes[left + 1];
-            const float    ia = axis == 0 ? ix : (axis == 1 ? iy : iz);
-            const float    oi = axis == 0 ? oix : (axis == 1 ? oiy : oiz);
+            const uint2 c0 = wf_node(S, (unsigned)left), c1 = wf_node(S, (unsigned)left + 8u);
+            const bool  ax0 = nd.y < 0x40000000u, ax2 = (int)nd.y < 0; // (two compares on the word itself, no shift)
+            const float ia = ax2 ? iz : (ax0 ? ix : iy);
+            const float oi = ax2 ? oiz : (ax0 ? oix : oiy);
             const float    tplane = __builtin_fmaf(__uint_as_float(nd.x), ia, -oi);
             // origin side of the plane: below it iff (split - o) > 0 iff tplane and d (hence 1/d) agree in sign
             const bool below = (tplane > 0.0f) == (ia > 0.0f);
-            const int  near = left + (below ? 0 : 1);
+            const int  near = left + (below ? 0 : 8);
             if (tplane <= 0.0f || !(tplane <= tmax_e)) {
                 node = near;
             } else if (tplane < tmin_e) {
-                node = left + (below ? 1 : 0);
+                node = left + (below ? 8 : 0);
             } else {
-                wf_stk_put(stk, sp, left + (below ? 1 : 0), tplane);
+                wf_stk_put(stk, sp, left + (below ? 8 : 0), tplane);
                 ++sp;
                 node = near;
                 tmax_e = tplane * (1.0f + RT_TRAV_EPS);
@@ -651,7 +665,9 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     }
     // ---- the light loop ----
     float              shadowMax = 0.0f, T = 0.0f;
+    float              shadowMax1 = 0.0f, T1 = 0.0f; // the same with the first query answered "occluded"
     int                ncast = 0;
+    unsigned           first_cast = 0; // the first query: its light << 24 | its place in the region's shadow queue
     unsigned long long soft_id = 0;
     if (SOFT && is_hit) {
         const int msaa = P.msaa;
@@ -677,7 +693,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
                 v = 3.33f * (0.3f - angle);
                 v = v < 0.0f ? 0.0f : v; // the std::max(shadowMax, softShadow) with softShadow >= 0 that follows
             }
-            if (v >= 0.0f) shadowMax = v;
+            if (v >= 0.0f) shadowMax = v, shadowMax1 = v;
             if (angle > 0.0f) {
                 if (s.spec) { // (a wave on a wall without highlights skips the block: walls are large)
                     f3 halfway = lightDir + s.viewDir;
@@ -693,11 +709,14 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
                 cast = SOFT || shadowMax != 1.0f;
             }
             T += shadowMax;
+            if (cast && ncast == 0) shadowMax1 = 1.0f; // raytracing.cpp:142-143 with that query occluded
+            T1 += shadowMax1;
             rec_v[li] = v;
         }
         // one queue for all lights: a wave of shadow rays is full whatever the share of each light
         const int pos = wf_append(g.n_sh, cast, per);
         if (cast) {
+            if (ncast == 0) first_cast = ((unsigned)li << 24) | (unsigned)pos; // (a region's queue has R * lights < 2^23 places)
             ++ncast;
             const f3  so = s.hp + lightDir * 0.001f; // raytracing.cpp:142
             const int tag = (li << 24) | j;
@@ -719,6 +738,12 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
             const float sm = L > 0 ? T * __fdiv_rn(P.ShadowFactor, (float)L) : 0.0f; // raytracing.cpp:102; no light, no term
             colour = (C - mk3(sm, sm, sm)) * wl;
             final_now = true;
+        } else if (!SOFT && ncast == 1) {
+            // A hit with one query needs no count of pending answers: both outcomes of the light loop are known
+            // here, the query's ray picks one (WF_TAG_SOLE in its tag) - no atomic, no per-light values read back.
+            *(float4*)rec = make_float4(C.x, C.y, C.z, wl);
+            *(uint4*)(rec + 16) = make_uint4(sl, __float_as_uint(T), __float_as_uint(T1), 0u);
+            *(unsigned*)&B.sh_org[sq0 + (first_cast & WF_TAG_SLOT)].w = (first_cast & 0xff000000u) | (unsigned)j | WF_TAG_SOLE;
         } else {
             *(float4*)rec = make_float4(C.x, C.y, C.z, wl);
             *(uint4*)(rec + 16) = make_uint4(sl, (unsigned)(ncast * per), 0u, 0u);
@@ -754,10 +779,17 @@ __device__ __forceinline__ unsigned wf_peek(const unsigned* p)
 // colour sums and records as arrays of structures (atomics to three words of one line: 11.2 ms).
 template <bool SOFT, class PT, class ACC>
 __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, size_t slot, const ACC& acc,
-                                               unsigned acc0, int li, bool occluded)
+                                               unsigned acc0, int li, bool occluded, bool sole)
 {
     const int      L = P.n_lights;
     unsigned char* rec = B.rec + slot * B.rec_stride;
+    if (!SOFT && sole) { // the hit's only query: the light loop was finished for both answers when the hit was shaded
+        const float4 c = *(const float4*)rec;
+        const uint4  u = *(const uint4*)(rec + 16);
+        const float  sm = __uint_as_float(occluded ? u.z : u.y) * __fdiv_rn(P.ShadowFactor, (float)L);
+        wf_acc_add(acc, acc0 + u.x, (mk3(c.x, c.y, c.z) - mk3(sm, sm, sm)) * c.w);
+        return;
+    }
     WfRecord*      R = (WfRecord*)rec;
     const float*   rec_v = (const float*)(rec + sizeof(WfRecord));
     unsigned*      rec_n = (unsigned*)(rec_v + L);
@@ -943,8 +975,8 @@ k_wf_trace(DScene S, WfBuffers B, const DParams* __restrict__ Pp, int q, int msa
                 const f3     dst = mk3(Pp->lights[3 * li], Pp->lights[3 * li + 1], Pp->lights[3 * li + 2]);
                 const bool   got = wf_traverse<true>(S, stk, o, dst - o, h, n_tests, n_nodes);
                 const WfAcc acc = {B.acc, (unsigned)B.n_samples};
-                wf_shadow_done<false>(*Pp, B, (size_t)q * B.cap + (size_t)r * B.R + (__float_as_int(ow.w) & 0xffffff), acc,
-                                      (unsigned)(r * B.S * msaa), li, got);
+                wf_shadow_done<false>(*Pp, B, (size_t)q * B.cap + (size_t)r * B.R + (__float_as_uint(ow.w) & WF_TAG_SLOT), acc,
+                                      (unsigned)(r * B.S * msaa), li, got, (__float_as_uint(ow.w) & WF_TAG_SOLE) != 0u);
             }
         }
     }
@@ -1300,8 +1332,8 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                 atomicAdd(&g_diag[6], (unsigned long long)(st.n_tests - t0_)), atomicAdd(&g_diag[7], (unsigned long long)(st.n_nodes - n0_));
             }
 #endif
-            wf_shadow_done<SOFT>(P, B, in0 + (__float_as_int(ow.w) & 0xffffff),
-                                 g.acc, g.acc0, li, got);
+            wf_shadow_done<SOFT>(P, B, in0 + (__float_as_uint(ow.w) & WF_TAG_SLOT),
+                                 g.acc, g.acc0, li, got, (__float_as_uint(ow.w) & WF_TAG_SOLE) != 0u);
             WF_SC(7);
         }
     }
