@@ -39,7 +39,7 @@ struct DNode {
 //   heads  one float4 per slot, the plane heads of slots 2p and 2p + 1 interleaved (tri_heads_keep):
 //            heads[2p]     = n0.x n1.x n0.y n1.y
 //            heads[2p + 1] = n0.z n1.z k0   k1        (n, k: the triangle's plane, scaled; zero for no triangle)
-//   edges  three float4: (ga, ka) s, (gb, kb) s, (s, -, -, -)      (tri_edges_keep)
+//   edges  three float4: (ga.x gb.x ga.y gb.y) s, (ga.z gb.z ka kb) s, (s, -, -, -)      (tri_edges_keep)
 //   tris   three float4, what the exact test takes:
 //            q0 = e1.x e1.y e1.z e2.x      e1 = v0 - v2, e2 = v1 - v2 (raytracing.cpp:366-368)
 //            q1 = e2.y e2.z v2.x v2.y
@@ -334,6 +334,7 @@ RT_PK(pk_rsub_hi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[
 RT_PK3(pk_fma_lo, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]")                 // a * b.lo + c
 RT_PK3(pk_fma_hi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]")  // a * b.hi + c
 RT_PK3(pk_fms_lo, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]") // a * b.lo - c
+RT_PK3(pk_fms_hi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]") // a * b.hi - c
 #undef RT_PK
 #undef RT_PK3
 
@@ -380,7 +381,9 @@ __device__ __forceinline__ void tri_heads_keep(const float4 h0, const float4 h1,
 // lane.  Where the plane is crossed decides a and b: with n = e1 x e2, ga = (e2 x n) / n.n and gb = (n x e1) / n.n,
 // a = ga . (P - v2) and b = gb . (P - v2) for a point P of the plane, and with P = o + t dir, t = -N / D:
 //   a D = (ga . o + ka) D - N (ga . dir),  ka = -ga . v2      (likewise b; all of it times the head's 1 / B)
-// - eight fused operations per coordinate from the head's D and N, no division.  The record holds (ga, ka) and
+// - eight fused operations per coordinate from the head's D and N, no division; the two coordinates go through the
+// halves of packed operations like the two heads of a pair (nine instructions for both; 3.11 -> 3.04 G vector
+// instructions per 4K frame of final.obj, its duration unchanged).  The record holds (ga, ka) and
 // (gb, kb) times s = 1 / max |component of ga, gb|, and s.  Again the decision only has to be safe: the reference
 // rejects on the SIGN of its a and b, and the sign of a rounded determinant is certain once the exact one
 // exceeds 7 * 2^-24 times the sum of the absolute triple products, which is at most |c|_1 |dir|_1 max|e2_j|
@@ -391,16 +394,20 @@ __device__ __forceinline__ void tri_heads_keep(const float4 h0, const float4 h1,
 // crossings only are decided on this rule.  Nothing is decided unless the sign of D is certain; a degenerate
 // triangle has a zero record: never dropped.  What is kept goes on to the exact test, so hits and their a, b, t
 // stay the reference's bits.
-__device__ __forceinline__ bool tri_edges_keep(const float4 E0, const float4 E1, const float s, f3 o, f3 d, float Dh,
-                                               float Nh, float eD, float eN)
+// The two coordinates travel in the halves of packed operations: E0 = ga.x gb.x ga.y gb.y, E1 = ga.z gb.z ka kb
+// (times s).  D2, N2: the D / B and N / B of the pair of heads the slot's head was tested in; SECOND: the slot
+// is the second of the pair.
+template <bool SECOND>
+__device__ __forceinline__ bool tri_edges_keep(const float4 E0, const float4 E1, const float s, const RayPairs& r, v2f D2,
+                                               v2f N2, float eD, float eN)
 {
-    const float Ao = __builtin_fmaf(E0.x, o.x, __builtin_fmaf(E0.y, o.y, __builtin_fmaf(E0.z, o.z, E0.w)));
-    const float Ad = __builtin_fmaf(E0.x, d.x, __builtin_fmaf(E0.y, d.y, E0.z * d.z));
-    const float Bo = __builtin_fmaf(E1.x, o.x, __builtin_fmaf(E1.y, o.y, __builtin_fmaf(E1.z, o.z, E1.w)));
-    const float Bd = __builtin_fmaf(E1.x, d.x, __builtin_fmaf(E1.y, d.y, E1.z * d.z));
-    const float Xa = __builtin_fmaf(Ao, Dh, -(Nh * Ad)), Xb = __builtin_fmaf(Bo, Dh, -(Nh * Bd));
+    const v2f gx = {E0.x, E0.y}, gy = {E0.z, E0.w}, gz = {E1.x, E1.y}, kk = {E1.z, E1.w};
+    const v2f Go = pk_fma_lo(gx, r.oxy, pk_fma_hi(gy, r.oxy, pk_fma_lo(gz, r.ozdx, kk))); // (ga . o + ka, gb . o + kb)
+    const v2f Gd = pk_fma_hi(gx, r.ozdx, pk_fma_lo(gy, r.dyz, pk_mul_hi(gz, r.dyz)));     // (ga . dir, gb . dir)
+    const v2f X = SECOND ? pk_fms_hi(Go, D2, pk_mul_hi(Gd, N2)) : pk_fms_lo(Go, D2, pk_mul_lo(Gd, N2)); // Go D - N Gd
+    const float    Dh = SECOND ? D2.y : D2.x;
     const unsigned sg = __float_as_uint(Dh) & 0x80000000u;
-    const float    xa = __uint_as_float(__float_as_uint(Xa) ^ sg), xb = __uint_as_float(__float_as_uint(Xb) ^ sg);
+    const float    xa = __uint_as_float(__float_as_uint(X.x) ^ sg), xb = __uint_as_float(__float_as_uint(X.y) ^ sg);
     const float    T = (eD * 2097152.0f) * eN; // 2^-18 so sd (eD = 2^-20 sd, eN = 2^-19 so)
     const float    aD = fabsf(Dh), lowD = aD - eD;
     const int      sure = lowD > 0.0f;

@@ -82,7 +82,7 @@ __host__ __device__ inline void kd_tri_extent(const float* vpos, const int32_t* 
 // strictly inside cb.
 __host__ __device__ inline bool kd_split_cost(const float* vpos, const int32_t* tri_vertex, const int32_t* list, int n,
                                               const KdBox& cb, double sa, int a, double pl, double c_trav,
-                                              double c_isect, double& cost, double& plane)
+                                              double c_isect, double c_empty, double& cost, double& plane)
 {
     const float plf = (float)pl;
     if (!((double)plf > cb.lo[a] && (double)plf < cb.hi[a])) return false;
@@ -96,7 +96,7 @@ __host__ __device__ inline bool kd_split_cost(const float* vpos, const int32_t* 
     KdBox bl = cb, br = cb;
     bl.hi[a] = plf, br.lo[a] = plf;
     cost = c_trav + c_isect * (kd_area(bl) * (double)nl + kd_area(br) * (double)nr) / sa;
-    if (nl == 0 || nr == 0) cost *= 0.8;
+    if (nl == 0 || nr == 0) cost *= c_empty;
     plane = (double)plf;
     return true;
 }
@@ -121,7 +121,7 @@ struct KdSplitResult {
 };
 struct KdSplitParams {
     KdBox  mesh_box;
-    double c_trav, c_isect;
+    double c_trav, c_isect, c_empty;
     int    leaf_target;
 };
 
@@ -234,7 +234,7 @@ k_kd_split(const float* __restrict__ vpos, const int32_t* __restrict__ tri_verte
             const double pl = upper ? mx : mn;
             if (!(pl > cb.lo[a] && pl < cb.hi[a])) continue;
             double cost, plane;
-            if (!kd_split_cost(vpos, tri_vertex, list, n, cb, sa, a, pl, prm.c_trav, prm.c_isect, cost, plane)) continue;
+            if (!kd_split_cost(vpos, tri_vertex, list, n, cb, sa, a, pl, prm.c_trav, prm.c_isect, prm.c_empty, cost, plane)) continue;
             if (cost < best) best = cost, best_c = c, best_plane = plane; // c ascends: ties keep the earlier one
         }
     }

@@ -272,6 +272,9 @@ __device__ unsigned long long g_sect[16];
 #define WF_SC(i) do { } while (0)
 #define WF_SC_END do { } while (0)
 #endif
+struct wf_false { static constexpr bool value = false; };
+struct wf_true { static constexpr bool value = true; };
+
 // A node's record.  The walk names a node by where its record lies, in bytes from the first (what an inner
 // node stores for its left child, and what goes on the stack): the address is the array plus that word, with no
 // index arithmetic per step.
@@ -355,6 +358,8 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
         for (int i = 0; i < cnt; i += 2) { // slots first + i and first + i + 1 (a list starts at an even slot)
             const float4* hp = S.heads + (first + i);
             float4        h0 = hp[0], h1 = hp[1];
+            // (the next pair asked for before this one is tested, so that a leaf's trips do not each wait a full
+            // load: 6.39 vs 6.20 ms - eight more live registers, five of them spilled, and the copies)
             // (the rest of a slot asked for with its head and waited for only by survivors: 8.08 vs 7.67 ms)
             const bool two = i + 1 < cnt;
             if (COUNT) n_tests += two ? 2u : 1u;
@@ -377,12 +382,12 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #endif
             if (!(keep0 || keep1)) continue;
             // what follows a head that lets the ray through: the edge record, then the exact test
-            auto candidate = [&](const int slot, const float Dh, const float Nh) -> bool {
+            auto candidate = [&](const int slot, auto second) -> bool {
                 {
                     const float4* er = S.edges + (size_t)3 * slot;
                     const float4  E0 = er[0], E1 = er[1];
                     const float   es = er[2].x;
-                    const bool    keep2 = tri_edges_keep(E0, E1, es, o, d, Dh, Nh, eDN.x, eDN.y);
+                    const bool    keep2 = tri_edges_keep<decltype(second)::value>(E0, E1, es, rp, D2, N2, eDN.x, eDN.y);
 #ifdef WF_DIAG
                     if (COUNT) {
                         const unsigned long long a_ = __ballot(1), m_ = __ballot(keep2);
@@ -411,8 +416,8 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
                 }
                 return false;
             };
-            if (keep0 && candidate(first + i, D2.x, N2.x)) return true;
-            if (keep1 && candidate(first + i + 1, D2.y, N2.y)) return true;
+            if (keep0 && candidate(first + i, wf_false())) return true;
+            if (keep1 && candidate(first + i + 1, wf_true())) return true;
         }
         // A pending subtree starts where the cell above it on the stack ends, give or take the
         // margins: entry t of the top entry = tmax_e / (1 + eps), and every deeper entry starts
