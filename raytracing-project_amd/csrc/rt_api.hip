@@ -511,6 +511,10 @@ struct RtScene {
     bool       refractive = false; // some material can spawn two child rays
     int        wf_grid_trace = 0, wf_grid_any = 0, wf_grid_pipe = 0;
     size_t     wf_lds = 0;
+    size_t     n_knodes = 0;
+    int        wf_cap_lo = 0;       // stack entries in LDS when one gives way to the copy of the tree's top
+    size_t     wf_single_sums = (size_t)-1, wf_single_top = 0;
+    int        wf_single_cap = 0;
     int        wf_cus = 0;                              // compute units of the device
     // the hand-out order of the single launch's regions (k_wf_order_*): the durations the last launch left, the
     // order made from them, the shape of the launch they belong to (0: none yet), and how many regions fit
@@ -1255,6 +1259,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
     s->d.texels = (const uint8_t*)s->d_texels;
     s->d.tri_rank = (const int32_t*)s->d_rank;
     s->d.knodes = (const uint2*)s->d_knodes;
+    s->n_knodes = knodes.size();
     s->d.n_nodes = (int)nodes.size();
     s->d.n_slots = (int)(slots.size() / RT_SLOT_F4);
     s->d.n_triangles = nt;
@@ -1578,7 +1583,8 @@ static int wf_prepare(RtScene* s)
     if (s->cfg.kd_stats)
         fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
                 (int)s->d.stack_entries, cap, s->wf_lds, per_cu);
-    const size_t deep = (size_t)(s->d.stack_entries - cap);
+    s->wf_cap_lo = (cap > 2 && !(s->cfg.stack_lds > 0)) ? cap - 1 : cap; // (an explicit RT_WF_STACK_LDS is kept)
+    const size_t deep = (size_t)(s->d.stack_entries - s->wf_cap_lo);
     const size_t blocks = (size_t)std::max(g_trace, std::max(g_any, g_pipe));
     const size_t n_deep = std::max<size_t>(deep * blocks * WF_BLOCK, 64);
     HIP_TRY(hipMalloc(&s->d_stk_spill, n_deep * WF_STACK_ENTRY_BYTES));
@@ -1739,17 +1745,51 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         S = std::max(32, std::min(S, WF_ACC_SAMPLES / P.msaa / 32 * 32)); // the region's colour sums live in LDS
     }
     // blocks the single launch can keep resident with its stacks and colour sums in LDS
-    const size_t lds_single = s->wf_lds + (size_t)S * P.msaa * 24;
+    // Beside them, where LDS is left: a copy of the tree's first levels (wf_node_pair).  A walk is a chain of
+    // dependent loads, and a record from LDS arrives in half the time of one from the vector L1; the nodes are
+    // numbered breadth first, so the first 2 KB are the top eight levels every walk starts with.  What fits
+    // without costing a resident block is taken, up to 8 KB; if that is less than 2 KB, one stack entry per
+    // thread gives way (final.obj 4K MSAA4: 5 entries 6.19 ms, 4 entries 6.27 ms, 4 entries + 2 KB of nodes 6.00 ms).
+    const size_t sums_bytes = (size_t)S * P.msaa * 24;
     int          grid_single = s->wf_grid_pipe;
     if (single) {
-        if (s->wf_single_lds != lds_single) {
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_pipeline<false, false>, WF_BLOCK, lds_single));
-            s->wf_single_grid = std::min(s->wf_grid_pipe, std::max(1, per_cu) * s->wf_cus);
-            s->wf_single_lds = lds_single;
+        if (s->wf_single_sums != sums_bytes) {
+            auto blocks_with = [&](size_t lds, int* per_cu) -> int {
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_wf_pipeline<false, false>, WF_BLOCK, lds));
+                return RT_OK;
+            };
+            const char*  top_env = getenv("RT_WF_TOP"); // bytes; 0 switches the copy off
+            const size_t top_max = std::min<size_t>((size_t)s->n_knodes * 8, top_env ? (size_t)atoi(top_env) & ~(size_t)7 : 8192);
+            const int    cap_hi = s->d.stk_cap, cap_lo = s->wf_cap_lo;
+            size_t       top_of[2] = {0, 0};
+            int          per_cu_of[2] = {0, 0};
+            for (int v = 0; v < 2; ++v) { // v = 0: every stack entry stays, v = 1: one gives way
+                const size_t stacks = (size_t)(v == 0 ? cap_hi : cap_lo) * WF_BLOCK * WF_STACK_ENTRY_BYTES;
+                int          rc2 = blocks_with(stacks + sums_bytes, &per_cu_of[v]);
+                if (rc2) return rc2;
+                for (size_t top = top_max; top > 0; top = top > 1024 ? ((top - 1) & ~(size_t)1023) : 0) {
+                    int per_cu = 0;
+                    if ((rc2 = blocks_with(stacks + sums_bytes + top, &per_cu))) return rc2;
+                    if (per_cu >= per_cu_of[v]) {
+                        top_of[v] = top;
+                        break;
+                    }
+                }
+            }
+            const bool full = top_of[0] >= std::min<size_t>(top_max, 2048);
+            const int  v = (full || cap_lo == cap_hi || per_cu_of[1] < per_cu_of[0] || top_of[1] < std::min<size_t>(top_max, 2048)) ? 0 : 1;
+            s->wf_single_cap = v == 0 ? cap_hi : cap_lo;
+            s->wf_single_top = top_of[v];
+            s->wf_single_lds = (size_t)s->wf_single_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + sums_bytes + s->wf_single_top;
+            s->wf_single_grid = std::min(s->wf_grid_pipe, std::max(1, per_cu_of[v]) * s->wf_cus);
+            s->wf_single_sums = sums_bytes;
+            if (s->cfg.kd_stats)
+                fprintf(stderr, "wavefront: single launch with %d stack entries and %zu B of nodes in LDS, %zu B per block, %d blocks per CU\n",
+                        s->wf_single_cap, s->wf_single_top, s->wf_single_lds, per_cu_of[v]);
         }
         grid_single = s->wf_single_grid;
     }
+    const size_t lds_single = s->wf_single_lds;
     // the single launch keeps one set of buffers per resident block, whatever the size of the frame
     const long long plan_slots = single ? std::min(n_slots, (long long)grid_single * S) : (n_slots + n_pipes - 1) / n_pipes;
     WfPlan pl = wf_plan(s, P, plan_slots, n_pipes, S, !single);
@@ -1786,10 +1826,12 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         WfLaunch A;
         if (P.msaa > 1 || !d_tri) C[0].s_tri = nullptr; // nobody reads the samples' triangles then
         A.S = s->d, A.P = P, A.B = C[0], A.slot0 = 0, A.n = (int)n_slots, A.n_regions = (int)((n_slots + S - 1) / S);
+        A.S.stk_cap = s->wf_single_cap;
         A.rgb = d_rgb, A.depth = d_depth, A.tri = d_tri, A.ctr = s->d_ctr;
         // Regions in the order of the durations the last launch of this shape measured, longest first
         // (k_wf_order_*); by index the first time, after a change of shape, and for launches of a few regions.
         A.order = nullptr, A.cost = nullptr;
+        A.top_bytes = (unsigned)s->wf_single_top;
         const bool feedback = s->wf_feedback && A.n_regions > pl.G;
         if (feedback) {
             if ((size_t)A.n_regions > s->wf_order_cap) {

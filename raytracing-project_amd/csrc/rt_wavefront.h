@@ -38,6 +38,8 @@
 
 #pragma clang fp contract(off)
 
+// (Blocks of 128 threads - half as many waves held at every stage barrier, twice as many blocks - take 6.9 ms per
+// 4K MSAA4 frame of final.obj against 6.2 ms, blocks of 512 threads 7.3 ms: -DWF_BLOCK=...)
 #ifndef WF_BLOCK
 #define WF_BLOCK 256
 #endif
@@ -181,6 +183,8 @@ struct WfStack {
     WfLdsEntries lds;
     uint2*       spill;
     int          cap;
+    WfLdsEntries top;       // k_wf_pipeline: a copy of the first top_bytes of the node array in LDS
+    unsigned     top_bytes; // (0: none)
 };
 
 // LDS layout per block: uint2 entry[cap][WF_BLOCK]
@@ -193,6 +197,7 @@ __device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_me
     k.lds = (WfLdsEntries)s_mem + threadIdx.x;
     const size_t deep = (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK;
     k.spill = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
+    k.top = (WfLdsEntries)s_mem, k.top_bytes = 0;
     return k;
 }
 
@@ -249,6 +254,13 @@ __device__ __forceinline__ void wf_stk_top2(const WfStack& k, int sp, uint2& top
 // tests (11.2 -> 7.8 per ray), all results unchanged - and the frame takes 9.2-9.4 ms as before: the
 // tests it saves are the cheapest ones, and the box is one more dependent load per leaf.
 // The exact test without its early returns directly behind the plane heads (no edge records): 7.70 vs 7.46 ms.
+// What the launch is sensitive to, measured by padding (final.obj 4K MSAA4, 6.28 ms): four / eight more vector
+// instructions per node step (+4 / +9 % of all) cost 2.2 / 3.2 %, twelve more per edge record nothing, one more
+// 8-byte load per node step (always a hit in the vector L1, +21 % vector memory instructions) 10 %.  The node
+// loop - every lane at work, one load per step and nothing to overlap it with but the step's own arithmetic - is
+// where time goes; the stages behind the plane heads run in its shadow.  Accordingly: the edge records in packed
+// pairs (-2.4 % vector instructions) and edge records of two loads instead of three (unscaled gradients with one
+// error bound per scene) changed no frame time, the latter lost 7 % on fin.obj, whose triangles differ most in size.
 #ifdef WF_DIAG
 // Diagnostic builds only (-DWF_DIAG): lane slots (wave trips x 64) of the node loop and of the triangle
 // loop of the counted launch; rt_api.hip prints them against the lanes that did work (final.obj 4K MSAA4:
@@ -283,6 +295,28 @@ __device__ __forceinline__ uint2 wf_node(const DScene& S, unsigned at)
     return *(const uint2*)((const char*)S.knodes + at);
 }
 
+// The same through the copy of the tree's first levels in LDS where the record lies in it (the two address
+// spaces in two branches, see wf_stk_put).  The records of the first levels are what every walk starts with
+// and what the far children popped last are; from LDS they arrive in about half the time of a hit in the vector L1.
+__device__ __forceinline__ uint2 wf_node(const DScene& S, const WfStack& k, unsigned at)
+{
+    if (at < k.top_bytes) {
+        const wf_u2 v = k.top[at >> 3];
+        return make_uint2(v.x, v.y);
+    }
+    return wf_node(S, at);
+}
+__device__ __forceinline__ void wf_node_pair(const DScene& S, const WfStack& k, unsigned at, uint2& c0, uint2& c1)
+{
+    // (from the copy only if every lane of the wave is in it - a wave with lanes on both sides would wait for
+    // both loads, and a branch per lane costs more than it saves: 6.08 ms per lane, 6.00 ms per wave)
+    if (__builtin_amdgcn_ballot_w64(at + 8u >= k.top_bytes) == 0ull) {
+        const WfLdsEntries p = k.top + (at >> 3);
+        const wf_u2        a = p[0], b = p[1];
+        c0 = make_uint2(a.x, a.y), c1 = make_uint2(b.x, b.y);
+    } else c0 = wf_node(S, at), c1 = wf_node(S, at + 8u);
+}
+
 template <bool ANY, bool COUNT = true>
 __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk, f3 o, f3 d, HitRec& h,
                                             unsigned& n_tests, unsigned& n_nodes)
@@ -307,7 +341,7 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
     }
     const RayPairs rp = {v2f{o.x, o.y}, v2f{o.z, d.x}, v2f{d.y, d.z}};
     for (;;) {
-        uint2 nd = wf_node(S, (unsigned)node);
+        uint2 nd = wf_node(S, stk, (unsigned)node);
         if (COUNT) ++n_nodes;
 #ifdef WF_DIAG
         if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
@@ -320,7 +354,8 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             // Both children lie side by side: their records are asked for before the plane decides which
             // one the walk takes, so the decision is made while the load is under way and the chain
             // from node to node is the load alone.
-            const uint2 c0 = wf_node(S, (unsigned)left), c1 = wf_node(S, (unsigned)left + 8u);
+            uint2 c0, c1;
+            wf_node_pair(S, stk, (unsigned)left, c0, c1);
             const bool  ax0 = nd.y < 0x40000000u, ax2 = (int)nd.y < 0; // (two compares on the word itself, no shift)
             const float ia = ax2 ? iz : (ax0 ? ix : iy);
             const float oi = ax2 ? oiz : (ax0 ? oix : oiy);
@@ -1155,6 +1190,7 @@ struct WfLaunch {
     DCounters* ctr;
     const int* order; // regions in the order they are handed out (null: by index), see k_wf_order_place
     unsigned*  cost;  // per region: how long it took this time (null: not recorded)
+    unsigned   top_bytes; // of the node array, from its start, that every block copies into LDS (0: none)
 };
 typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
 
@@ -1200,7 +1236,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     const DScene    S = wf_ld(A->S);
     const WfBuffers B = wf_ld(A->B);
     const auto&     P = A->P;
-    const WfStack   stk = wf_stack(S, s_mem);
+    WfStack         stk = wf_stack(S, s_mem);
     const int       msaa = P.msaa;
     const int       n_slots = A->n - r * B.S; // pixel slots from the region's first to the end of the frame part
     WfRegion<WfAccL> g;
@@ -1212,6 +1248,8 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     const int    ms = msaa == 16 ? 4 : (msaa == 4 ? 2 : 0); // msaa is 1, 4 or 16
     g.acc.at = (WfLdsSums)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES); // after the stacks
     g.acc.n = (unsigned)(B.S * msaa), g.acc0 = 0;
+    stk.top = (WfLdsEntries)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + (size_t)B.S * msaa * 24); // after the sums
+    stk.top_bytes = A->top_bytes;
     // (what is read from LDS is the same for every lane; said so, it lives in scalar registers and
     // not, as a vector register per value, in scratch during the walks)
     int n_first = B.S, n_sh = 0;
@@ -1504,6 +1542,15 @@ k_wf_pipeline(WfLaunch)
     // hundred KB (11.5 -> 10.6 ms per 4K frame against a set per region), and the workspace does
     // not grow with the frame.
     const int qr = blockIdx.x;
+    { // the tree's first levels into LDS (the loop's first barrier comes before any walk)
+        const WfLaunchC A = wf_args();
+        const unsigned  n_top = A->top_bytes >> 3;
+        const WfLdsEntries top = (WfLdsEntries)(s_mem + (size_t)A->S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + (size_t)A->B.S * A->P.msaa * 24);
+        for (unsigned i = threadIdx.x; i < n_top; i += WF_BLOCK) {
+            const uint2 v = A->S.knodes[i];
+            top[i] = wf_u2{v.x, v.y};
+        }
+    }
 #ifdef WF_SECT
     if (threadIdx.x < 10) sh.sect[threadIdx.x] = 0;
 #endif
