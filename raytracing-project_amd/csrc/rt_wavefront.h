@@ -176,7 +176,11 @@ __global__ void __launch_bounds__(1024) k_wf_worklist(WfBuffers B, int q, int pa
 // LDS part serves nearly all pushes and pops while the tree's full depth stays available; LDS per
 // block, and with it the number of resident waves, does not grow with the depth of the tree.
 // (Until the node index took 32 bits the entry was a 16-bit node beside a float in two arrays: two
-// LDS instructions and two addresses per push, and no scene beyond 65535 nodes on this path.)
+// LDS instructions and two addresses per push, and no scene beyond 65535 nodes on this path.
+// The far child's record itself on the stack, twelve bytes per entry, so that a pop need not fetch it - one load
+// less in the chain of every pop: 6.32 ms per 4K MSAA4 frame of final.obj against 6.00 ms with the LDS that is
+// there, and 1.46 against 1.43 ms for a 1080p frame whose five entries all fit either way: the push has to wait
+// for the children's records, which the push of an index does not.)
 typedef unsigned __attribute__((ext_vector_type(2))) wf_u2; // (a plain vector type: assignable across address spaces)
 typedef __attribute__((address_space(3))) wf_u2* WfLdsEntries; // typed as LDS: ds_read_b64 / ds_write_b64, not flat
 struct WfStack {
