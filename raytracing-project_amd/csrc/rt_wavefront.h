@@ -262,7 +262,10 @@ __device__ __forceinline__ void wf_stk_top2(const WfStack& k, int sp, uint2& top
 // instructions per node step (+4 / +9 % of all) cost 2.2 / 3.2 %, twelve more per edge record nothing, one more
 // 8-byte load per node step (always a hit in the vector L1, +21 % vector memory instructions) 10 %.  The node
 // loop - every lane at work, one load per step and nothing to overlap it with but the step's own arithmetic - is
-// where time goes; the stages behind the plane heads run in its shadow.  Accordingly: the edge records in packed
+// where time goes; the stages behind the plane heads run in its shadow (eight more vector instructions per trip
+// of the triangle loop: nothing; one more load per trip, from another array: 1.6 %).  The chosen child's record
+// alone, fetched after the plane has decided (8 bytes per step instead of 16, the decision no longer hidden
+// behind the load): 6.10 against 6.14 ms, no difference.  Accordingly: the edge records in packed
 // pairs (-2.4 % vector instructions) and edge records of two loads instead of three (unscaled gradients with one
 // error bound per scene) changed no frame time, the latter lost 7 % on fin.obj, whose triangles differ most in size.
 #ifdef WF_DIAG
