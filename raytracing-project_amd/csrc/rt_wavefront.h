@@ -189,6 +189,7 @@ struct WfStack {
     int          cap;
     WfLdsEntries top;       // k_wf_pipeline: a copy of the first top_bytes of the node array in LDS
     unsigned     top_bytes; // (0: none)
+    unsigned     top_pairs; // a pair of records that starts before this offset lies in the copy (0: none does)
 };
 
 // LDS layout per block: uint2 entry[cap][WF_BLOCK]
@@ -201,7 +202,7 @@ __device__ __forceinline__ WfStack wf_stack(const DScene& S, unsigned char* s_me
     k.lds = (WfLdsEntries)s_mem + threadIdx.x;
     const size_t deep = (size_t)(S.stack_entries - S.stk_cap) * WF_BLOCK;
     k.spill = S.stk_spill + (size_t)blockIdx.x * deep + threadIdx.x;
-    k.top = (WfLdsEntries)s_mem, k.top_bytes = 0;
+    k.top = (WfLdsEntries)s_mem, k.top_bytes = 0, k.top_pairs = 0;
     return k;
 }
 
@@ -317,8 +318,8 @@ __device__ __forceinline__ void wf_node_pair(const DScene& S, const WfStack& k, 
 {
     // (from the copy only if every lane of the wave is in it - a wave with lanes on both sides would wait for
     // both loads, and a branch per lane costs more than it saves: 6.08 ms per lane, 6.00 ms per wave)
-    if (__builtin_amdgcn_ballot_w64(at + 8u >= k.top_bytes) == 0ull) {
-        const WfLdsEntries p = k.top + (at >> 3);
+    if (__builtin_amdgcn_ballot_w64(at >= k.top_pairs) == 0ull) {
+        const WfLdsEntries p = (WfLdsEntries)((__attribute__((address_space(3))) unsigned char*)k.top + at); // (a multiple of 8)
         const wf_u2        a = p[0], b = p[1];
         c0 = make_uint2(a.x, a.y), c1 = make_uint2(b.x, b.y);
     } else c0 = wf_node(S, at), c1 = wf_node(S, at + 8u);
@@ -333,13 +334,12 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
     int   best_orig = -1;
     int   node = 0, sp = 0;
     float tmin_e = 0.0f, tmax_e = RT_FLT_MAX; // entry / exit t of the current cell, margins applied
-    // per axis: 1/d, o/d and whether d > 0.  A zero component gets a huge positive stand-in:
-    // the plane is then "reached" only at +-infinity-like t with the correct side.
+    // per axis 1/d.  A zero component gets a huge positive stand-in: the plane is then "reached" only at
+    // +-infinity-like t with the correct side.
     const float big = 1e18f;
     const float ix = d.x != 0.0f ? __builtin_amdgcn_rcpf(d.x) : big,
                 iy = d.y != 0.0f ? __builtin_amdgcn_rcpf(d.y) : big,
                 iz = d.z != 0.0f ? __builtin_amdgcn_rcpf(d.z) : big;
-    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
     v2f eDN; // the plane heads' error bounds for this ray
     {
         float eD, eN;
@@ -357,30 +357,30 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
 #ifdef WF_DIAG
             if (COUNT) { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_diag[0], 64ull); }
 #endif
-            const int left = (int)(nd.y & 0x3fffffffu); // where the left child's record is, in bytes from the first
+            const unsigned left = nd.y & 0x3fffffffu; // where the left child's record is, in bytes from the first
             // Both children lie side by side: their records are asked for before the plane decides which
             // one the walk takes, so the decision is made while the load is under way and the chain
             // from node to node is the load alone.
             uint2 c0, c1;
-            wf_node_pair(S, stk, (unsigned)left, c0, c1);
+            wf_node_pair(S, stk, left, c0, c1);
             const bool  ax0 = nd.y < 0x40000000u, ax2 = (int)nd.y < 0; // (two compares on the word itself, no shift)
             const float ia = ax2 ? iz : (ax0 ? ix : iy);
-            const float oi = ax2 ? oiz : (ax0 ? oix : oiy);
-            const float    tplane = __builtin_fmaf(__uint_as_float(nd.x), ia, -oi);
+            const float oa = ax2 ? o.z : (ax0 ? o.x : o.y);
+            // (o / d per axis kept beside 1 / d for one fused operation here: the compiler did not keep the three
+            // products in registers but formed them again at every step)
+            const float tplane = (__uint_as_float(nd.x) - oa) * ia;
             // origin side of the plane: below it iff (split - o) > 0 iff tplane and d (hence 1/d) agree in sign
             const bool below = (tplane > 0.0f) == (ia > 0.0f);
-            const int  near = left + (below ? 0 : 8);
-            if (tplane <= 0.0f || !(tplane <= tmax_e)) {
-                node = near;
-            } else if (tplane < tmin_e) {
-                node = left + (below ? 8 : 0);
-            } else {
-                wf_stk_put(stk, sp, left + (below ? 8 : 0), tplane);
-                ++sp;
-                node = near;
-                tmax_e = tplane * (1.0f + RT_TRAV_EPS);
+            unsigned   sel = below ? 0u : 8u; // the child the walk goes on with, as its place in the pair: the near one ...
+            if (tplane > 0.0f && tplane <= tmax_e) {
+                if (tplane < tmin_e) sel ^= 8u; // ... the far one alone, if the plane lies before the cell's stretch of the ray
+                else {                          // ... or both: the far one waits on the stack
+                    wf_stk_put(stk, sp, (int)(left + (sel ^ 8u)), tplane);
+                    ++sp;
+                    tmax_e = tplane * (1.0f + RT_TRAV_EPS);
+                }
             }
-            nd = node == left ? c0 : c1;
+            nd = sel == 0u ? c0 : c1;
             if (COUNT) ++n_nodes;
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
@@ -1257,6 +1257,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     g.acc.n = (unsigned)(B.S * msaa), g.acc0 = 0;
     stk.top = (WfLdsEntries)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + (size_t)B.S * msaa * 24); // after the sums
     stk.top_bytes = A->top_bytes;
+    stk.top_pairs = __builtin_amdgcn_readfirstlane(A->top_bytes >= 16u ? A->top_bytes - 8u : 0u);
     // (what is read from LDS is the same for every lane; said so, it lives in scalar registers and
     // not, as a vector register per value, in scratch during the walks)
     int n_first = B.S, n_sh = 0;
