@@ -1353,6 +1353,10 @@ static int make_dparams(const RtParams* p, const float* camera, const float* lig
     d->backgroundlighting = p->backgroundlighting;
     d->diffusePower = p->diffusePower;
     d->ShadowFactor = p->ShadowFactor;
+    {
+        volatile float q = n_lights > 0 ? p->ShadowFactor / (float)n_lights : 0.0f; // (one rounded float division, as the kernels made it per hit)
+        d->shadow_per_light = q;
+    }
     memcpy(d->bg, p->backgroundColor, 12);
     if (camera) memcpy(d->cam, camera, sizeof d->cam);
     if (n_lights) memcpy(d->lights, lights, sizeof(float) * 3 * (size_t)n_lights);

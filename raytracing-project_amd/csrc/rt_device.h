@@ -72,7 +72,8 @@ struct DScene {
 
 struct DParams {
     int32_t W, H, msaa, n_lights;
-    float   backgroundlighting, diffusePower, ShadowFactor, pad0;
+    float   backgroundlighting, diffusePower, ShadowFactor;
+    float   shadow_per_light; // ShadowFactor / n_lights as the host's float division gives it (raytracing.cpp:102); 0 without lights
     float   bg[3];
     float   pad1;
     int32_t tile_w, tile_h, rank, world;

@@ -715,6 +715,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     // ---- the light loop ----
     float              shadowMax = 0.0f, T = 0.0f;
     float              shadowMax1 = 0.0f, T1 = 0.0f; // the same with the first query answered "occluded"
+    float4             v4 = make_float4(-1.0f, -1.0f, -1.0f, -1.0f); // what the first four lights' angles set shadowMax to
     int                ncast = 0;
     unsigned           first_cast = 0; // the first query: its light << 24 | its place in the region's shadow queue
     unsigned long long soft_id = 0;
@@ -760,7 +761,11 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
             T += shadowMax;
             if (cast && ncast == 0) shadowMax1 = 1.0f; // raytracing.cpp:142-143 with that query occluded
             T1 += shadowMax1;
-            rec_v[li] = v;
+            // (what the angles set shadowMax to is written behind the loop, and only where a record is left: a store
+            // per light into the record of every hit dirtied a line per hit, 40 % of them for hits that leave no
+            // record at all.  li is the same for every lane: the compares are scalar.)
+            v4.x = li == 0 ? v : v4.x, v4.y = li == 1 ? v : v4.y, v4.z = li == 2 ? v : v4.z, v4.w = li == 3 ? v : v4.w;
+            if (li >= 4) rec_v[li] = v;
         }
         // one queue for all lights: a wave of shadow rays is full whatever the share of each light
         const int pos = wf_append(g.n_sh, cast, per);
@@ -784,7 +789,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
     }
     if (is_hit) {
         if (ncast == 0) { // no answer can change it: final
-            const float sm = L > 0 ? T * __fdiv_rn(P.ShadowFactor, (float)L) : 0.0f; // raytracing.cpp:102; no light, no term
+            const float sm = L > 0 ? T * P.shadow_per_light : 0.0f; // raytracing.cpp:102; no light, no term
             colour = (C - mk3(sm, sm, sm)) * wl;
             final_now = true;
         } else if (!SOFT && ncast == 1) {
@@ -796,6 +801,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
         } else {
             *(float4*)rec = make_float4(C.x, C.y, C.z, wl);
             *(uint4*)(rec + 16) = make_uint4(sl, (unsigned)(ncast * per), 0u, 0u);
+            *(float4*)rec_v = v4; // (a record with queries has lights: its stride holds at least these 16 bytes)
             if (SOFT) {
                 unsigned* rec_n = (unsigned*)(rec_v + L);
                 for (int x = 0; x < ((L + 3) >> 2); ++x) rec_n[x] = 0u;
@@ -835,7 +841,7 @@ __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, 
     if (!SOFT && sole) { // the hit's only query: the light loop was finished for both answers when the hit was shaded
         const float4 c = *(const float4*)rec;
         const uint4  u = *(const uint4*)(rec + 16);
-        const float  sm = __uint_as_float(occluded ? u.z : u.y) * __fdiv_rn(P.ShadowFactor, (float)L);
+        const float  sm = __uint_as_float(occluded ? u.z : u.y) * P.shadow_per_light;
         wf_acc_add(acc, acc0 + u.x, (mk3(c.x, c.y, c.z) - mk3(sm, sm, sm)) * c.w);
         return;
     }
@@ -879,7 +885,7 @@ __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, 
         }
         T += shadowMax;
     }
-    const float sm = T * __fdiv_rn(P.ShadowFactor, (float)L);
+    const float sm = T * P.shadow_per_light;
     wf_acc_add(acc, sample, (mk3(c.x, c.y, c.z) - mk3(sm, sm, sm)) * c.w);
 }
 
@@ -1252,7 +1258,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     g.base = (size_t)qr * B.R, g.sample0 = (size_t)qr * B.S * msaa;
     g.slot_base = A->slot0 + (long long)r * B.S;
     g.lvl0 = (size_t)__builtin_amdgcn_readfirstlane((level & 1) * B.cap) + g.base;
-    g.n_child = &sh->child[(level + 1) % 3], g.n_sh = &sh->shd[level % 3];
+    g.n_child = nullptr, g.n_sh = nullptr; // (set where they are used, below)
     const size_t in0 = (size_t)__builtin_amdgcn_readfirstlane(((level + 1) & 1) * B.cap) + g.base; // the level before
     const int    ms = msaa == 16 ? 4 : (msaa == 4 ? 2 : 0); // msaa is 1, 4 or 16
     g.acc.at = (WfLdsSums)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES); // after the stacks
@@ -1358,6 +1364,12 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                     else if (msaa > 1) meta = wf_meta((unsigned)((B.hit_list[(size_t)qr * B.S + (j >> ms)].x << ms) + (j & (msaa - 1))), 0u, 0u);
                     else meta = wf_meta((unsigned)j, 0u, 0u);
                 }
+                // (the two counters' addresses are formed here, from a level the compiler cannot look through: formed
+                // at the top of the stage they sat in a vector register each - the same for every lane - that was
+                // spilled before the walks and fetched back from scratch memory at every light of every batch)
+                int lvl = level;
+                asm volatile("" : "+s"(lvl));
+                g.n_child = &sh->child[(lvl + 1) % 3], g.n_sh = &sh->shd[lvl % 3];
                 wf_shade_ray<SOFT>(S, P, B, out, g, valid, j, o, dir, w, ni, meta, got, h.slot, h.a, h.b, h.t,
                                    st.n_shaded, st.n_child);
             }
