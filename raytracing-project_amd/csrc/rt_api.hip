@@ -1614,7 +1614,7 @@ static size_t wf_rec_stride(int L, int ns)
 // Bytes per region: `multi` adds what only the one-launch-per-stage path uses.
 static size_t wf_region_bytes(long long R, int S, int msaa, int L, int ns, bool multi)
 {
-    const size_t rays = 2 * (16 + 16 + 4);
+    const size_t rays = 2 * (12 + 12 + 12);
     const size_t shadow = 2 * (size_t)L * ns * 16 * (ns > 1 ? 2 : 1);
     const size_t rec = 2 * wf_rec_stride(L, ns);
     return (size_t)R * (rays + shadow + rec + (multi ? 16 : 0)) + (size_t)S * msaa * (3 * 8 + 4 + 4) +
@@ -1659,7 +1659,7 @@ static size_t wf_chunk_bytes(const WfPlan& pl, int L, bool multi, size_t* off)
         ++k;
         need += align256(bytes);
     };
-    for (int q = 0; q < 2; ++q) take(cap * 16), take(cap * 16), take(cap * 4), take(G * 4); // 0..7 ray queues
+    for (int q = 0; q < 2; ++q) take(cap * 12), take(cap * 12), take(cap * 12), take(G * 4); // 0..7 ray queues: origin, destination, aux
     take(multi ? cap * 16 : 0);                                   // 8 hits
     take(2 * cap * 16 * (size_t)L * pl.ns);                       // 9 sh_org
     take(pl.ns > 1 ? 2 * cap * 16 * (size_t)L * pl.ns : 0);       // 10 sh_dst
@@ -1680,9 +1680,9 @@ static void wf_carve(unsigned char* m, const WfPlan& pl, int L, WfBuffers* B, un
                      const size_t* off)
 {
     for (int q = 0; q < 2; ++q) {
-        B->rays[q].o_w = (float4*)(m + off[4 * q]);
-        B->rays[q].d_ni = (float4*)(m + off[4 * q + 1]);
-        B->rays[q].meta = (unsigned*)(m + off[4 * q + 2]);
+        B->rays[q].o = (WfVec3*)(m + off[4 * q]);
+        B->rays[q].d = (WfVec3*)(m + off[4 * q + 1]);
+        B->rays[q].aux = (WfRayAux*)(m + off[4 * q + 2]);
         B->rays[q].cnt = (int*)(m + off[4 * q + 3]);
     }
     B->hits = (float4*)(m + off[8]);

@@ -82,11 +82,23 @@ struct WfShared {
 // One level's rays (structure of arrays); region r occupies [r * R, (r + 1) * R).
 // meta: bits 0-15 the sample (numbered inside the region), 16-18 the level k,
 // 19-26 the route from the camera ray (the soft-shadow generator's key).
+// Three arrays of twelve bytes per ray: what the walk needs (origin, destination) apart from what only the shading
+// needs afterwards (weight, prev_Ni, meta) - the shading fetches its part after the walk rather than carry it
+// through, and as the fourth words of the first two arrays plus a third array that fetch touched eighteen cache
+// lines per wave, most of them gone from the L2 by then; as one array it touches six.
+struct WfVec3 {
+    float x, y, z;
+};
+struct WfRayAux {
+    float    w;  // path weight
+    float    ni; // prev_Ni
+    unsigned meta;
+};
 struct WfRays {
-    float4*   o_w;  // origin xyz, path weight
-    float4*   d_ni; // destination xyz, prev_Ni
-    unsigned* meta;
-    int*      cnt;  // [G] rays in each region
+    WfVec3*   o;   // origin
+    WfVec3*   d;   // destination
+    WfRayAux* aux;
+    int*      cnt; // [G] rays in each region
 };
 
 __device__ __forceinline__ unsigned wf_meta(unsigned sample, unsigned k, unsigned route)
@@ -503,7 +515,10 @@ __device__ __forceinline__ int wf_append(int* lds_counter, bool mine, int per = 
     int       base = 0;
     if (lane == leader) base = atomicAdd(lds_counter, __popcll(m) * per);
     base = __shfl(base, leader);
-    return mine ? base + __popcll(m & ((1ull << lane) - 1ull)) * per : -1;
+    // (the lanes of m below this one, by the instruction pair made for it: written as a popcount under the mask
+    // (1 << lane) - 1 the mask was formed once per launch, spilled, and fetched back from scratch memory at every append)
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    return mine ? base + before * per : -1;
 }
 
 // v in units of 2^-32, rounded to nearest even: llrint((double)v * 2^32) without the double arithmetic
@@ -700,16 +715,16 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
         int pos = wf_append(g.n_child, hasA);
         if (hasA && pos < B.R) { // cannot exceed R by construction; the guard keeps a bug from writing outside
             const size_t p = g.base + pos;
-            out.o_w[p] = make_float4(a_o.x, a_o.y, a_o.z, a_w);
-            out.d_ni[p] = make_float4(a_d.x, a_d.y, a_d.z, n2);
-            out.meta[p] = wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | a_kind : 0u);
+            out.o[p] = WfVec3{a_o.x, a_o.y, a_o.z};
+            out.d[p] = WfVec3{a_d.x, a_d.y, a_d.z};
+            out.aux[p] = WfRayAux{a_w, n2, wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | a_kind : 0u)};
         }
         pos = wf_append(g.n_child, hasB);
         if (hasB && pos < B.R) {
             const size_t p = g.base + pos;
-            out.o_w[p] = make_float4(b_o.x, b_o.y, b_o.z, b_w);
-            out.d_ni[p] = make_float4(b_d.x, b_d.y, b_d.z, n2);
-            out.meta[p] = wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | 3u : 0u);
+            out.o[p] = WfVec3{b_o.x, b_o.y, b_o.z};
+            out.d[p] = WfVec3{b_d.x, b_d.y, b_d.z};
+            out.aux[p] = WfRayAux{b_w, n2, wf_meta(sl, (unsigned)(k + 1), SOFT ? ((route & 0x3fu) << 2) | 3u : 0u)};
         }
     }
     // ---- the light loop ----
@@ -955,9 +970,9 @@ k_wf_gen_centre(DParams P, WfBuffers B, int q, long long slot0, int n, DCounters
         if (valid) {
             f3 o, d;
             pixel_ray(P, (double)x, (double)y, o, d);
-            out.o_w[base + pos] = make_float4(o.x, o.y, o.z, 1.0f);
-            out.d_ni[base + pos] = make_float4(d.x, d.y, d.z, 1.0f); // prev_Ni = 1.0f (main.cpp:528)
-            out.meta[base + pos] = wf_meta((unsigned)j, 0u, 0u);
+            out.o[base + pos] = WfVec3{o.x, o.y, o.z};
+            out.d[base + pos] = WfVec3{d.x, d.y, d.z};
+            out.aux[base + pos] = WfRayAux{1.0f, 1.0f, wf_meta((unsigned)j, 0u, 0u)}; // prev_Ni = 1.0f (main.cpp:528)
         }
     }
     __syncthreads();
@@ -1018,7 +1033,7 @@ k_wf_trace(DScene S, WfBuffers B, const DParams* __restrict__ Pp, int q, int msa
             ++n_rays;
             if (!ANY) {
                 const size_t i = (size_t)r * B.R + idx;
-                const float4 ow = B.rays[q].o_w[i], dn = B.rays[q].d_ni[i];
+                const WfVec3 ow = B.rays[q].o[i], dn = B.rays[q].d[i];
                 const f3     o = mk3(ow.x, ow.y, ow.z);
                 const bool   got = wf_traverse<false>(S, stk, o, mk3(dn.x, dn.y, dn.z) - o, h, n_tests, n_nodes);
                 B.hits[i] = make_float4(__int_as_float(got ? h.slot : -1), h.a, h.b, h.t);
@@ -1066,7 +1081,7 @@ k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth
         bool       got = false;
         int        x = 0, y = 0, slot = 0;
         if (valid) {
-            slot = (int)(in.meta[base + j] & 0xffffu);
+            slot = (int)(in.aux[base + j].meta & 0xffffu);
             const float4 hit = B.hits[base + j];
             got = __float_as_int(hit.x) >= 0;
             slot_to_pixel(P, slot0 + (long long)r * B.S + slot, x, y);
@@ -1083,9 +1098,9 @@ k_wf_msaa_emit(DParams P, WfBuffers B, long long slot0, float* rgb, float* depth
                 f3          o, d;
                 pixel_ray(P, (double)x + (double)ox, (double)y + (double)oy, o, d);
                 const size_t p = base + pos + s;
-                out.o_w[p] = make_float4(o.x, o.y, o.z, 1.0f);
-                out.d_ni[p] = make_float4(d.x, d.y, d.z, 1.0f);
-                out.meta[p] = wf_meta((unsigned)(slot * P.msaa + s), 0u, 0u);
+                out.o[p] = WfVec3{o.x, o.y, o.z};
+                out.d[p] = WfVec3{d.x, d.y, d.z};
+                out.aux[p] = WfRayAux{1.0f, 1.0f, wf_meta((unsigned)(slot * P.msaa + s), 0u, 0u)};
             }
         }
     }
@@ -1117,7 +1132,11 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level, long long slot0, DCounte
         const size_t i = g.base + j;
         unsigned     meta = 0;
         float4       ow = make_float4(0, 0, 0, 0), dn = make_float4(0, 0, 0, 0), hit = make_float4(0, 0, 0, 0);
-        if (valid) meta = in.meta[i], ow = in.o_w[i], dn = in.d_ni[i], hit = B.hits[i];
+        if (valid) {
+            const WfVec3   ov = in.o[i], dv = in.d[i];
+            const WfRayAux ax = in.aux[i];
+            meta = ax.meta, ow = make_float4(ov.x, ov.y, ov.z, ax.w), dn = make_float4(dv.x, dv.y, dv.z, ax.ni), hit = B.hits[i];
+        }
         const f3 o = mk3(ow.x, ow.y, ow.z);
         wf_shade_ray<false>(S, P, B, out, g, valid, j, o, mk3(dn.x, dn.y, dn.z) - o, ow.w, dn.w, meta,
                             __float_as_int(hit.x) >= 0, __float_as_int(hit.x), hit.y, hit.z, hit.w, n_shaded, n_child);
@@ -1306,7 +1325,7 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             int  xy = 0;
             if (kind == WF_ST_LEVEL) {
                 if (valid) {
-                    const float4 ow = in.o_w[g.base + idx], dn = in.d_ni[g.base + idx];
+                    const WfVec3 ow = in.o[g.base + idx], dn = in.d[g.base + idx];
                     o = mk3(ow.x, ow.y, ow.z), dst = mk3(dn.x, dn.y, dn.z);
                 }
             } else {
@@ -1360,7 +1379,10 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
                 float    w = 1.0f, ni = 1.0f; // prev_Ni = 1.0f for camera rays (main.cpp:528)
                 unsigned meta = 0;
                 if (valid) {
-                    if (kind == WF_ST_LEVEL) w = in.o_w[g.base + j].w, ni = in.d_ni[g.base + j].w, meta = in.meta[g.base + j];
+                    if (kind == WF_ST_LEVEL) {
+                        const WfRayAux ax = in.aux[g.base + j];
+                        w = ax.w, ni = ax.ni, meta = ax.meta;
+                    }
                     else if (msaa > 1) meta = wf_meta((unsigned)((B.hit_list[(size_t)qr * B.S + (j >> ms)].x << ms) + (j & (msaa - 1))), 0u, 0u);
                     else meta = wf_meta((unsigned)j, 0u, 0u);
                 }
