@@ -513,6 +513,7 @@ struct RtScene {
     size_t     wf_lds = 0;
     size_t     n_knodes = 0;
     int        wf_cap_lo = 0;       // stack entries in LDS when one gives way to the copy of the tree's top
+    size_t     wf_lds_per_cu = 0;
     size_t     wf_single_sums = (size_t)-1, wf_single_top = 0;
     int        wf_single_cap = 0;
     int        wf_cus = 0;                              // compute units of the device
@@ -1587,7 +1588,7 @@ static int wf_prepare(RtScene* s)
     if (s->cfg.kd_stats)
         fprintf(stderr, "wavefront: stack %d entries (%d in LDS, %zu B per block), pipeline %d blocks per CU\n",
                 (int)s->d.stack_entries, cap, s->wf_lds, per_cu);
-    s->wf_cap_lo = (cap > 2 && !(s->cfg.stack_lds > 0)) ? cap - 1 : cap; // (an explicit RT_WF_STACK_LDS is kept)
+    s->wf_cap_lo = s->cfg.stack_lds > 0 ? cap : std::min(cap, 2); // the fewest the single launch may settle for (an explicit RT_WF_STACK_LDS is kept)
     const size_t deep = (size_t)(s->d.stack_entries - s->wf_cap_lo);
     const size_t blocks = (size_t)std::max(g_trace, std::max(g_any, g_pipe));
     const size_t n_deep = std::max<size_t>(deep * blocks * WF_BLOCK, 64);
@@ -1595,6 +1596,7 @@ static int wf_prepare(RtScene* s)
     s->d.stk_spill = (uint2*)s->d_stk_spill;
     s->wf_grid_trace = g_trace, s->wf_grid_any = g_any, s->wf_grid_pipe = g_pipe;
     s->wf_cus = prop.multiProcessorCount;
+    s->wf_lds_per_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     return RT_OK;
 }
 
@@ -1752,37 +1754,59 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     // Beside them, where LDS is left: a copy of the tree's first levels (wf_node_pair).  A walk is a chain of
     // dependent loads, and a record from LDS arrives in half the time of one from the vector L1; the nodes are
     // numbered breadth first, so the first 2 KB are the top eight levels every walk starts with.  What fits
-    // without costing a resident block is taken, up to 8 KB; if that is less than 2 KB, one stack entry per
+    // without costing a resident block is taken, up to 8 KB; if that is less than 1 KB, one stack entry per
     // thread gives way (final.obj 4K MSAA4: 5 entries 6.19 ms, 4 entries 6.27 ms, 4 entries + 2 KB of nodes 6.00 ms).
-    const size_t sums_bytes = (size_t)S * P.msaa * 24;
+    // The records' pending counts, one byte per ray slot and level parity, in LDS where a region's queue is short
+    // enough (no refraction: a ray slot per sample) and the lights are at most four: an LDS atomic per answer
+    // instead of a transaction with the memory fabric.  They are part of what the block's other LDS contents leave.
+    const long long R_plan = (long long)S * P.msaa * (s->refractive ? 16 : 1);
+    const size_t    pend_bytes = (single && P.soft_n == 0 && L <= 4 && R_plan <= 1024 && !getenv("RT_WF_NO_LDS_PENDING")) ? (size_t)((R_plan + 3) & ~3LL) : 0;
+    const size_t sums_bytes = (size_t)S * P.msaa * 24 + 2 * pend_bytes; // (kept as one figure: what has to fit beside the stacks)
     int          grid_single = s->wf_grid_pipe;
     if (single) {
         if (s->wf_single_sums != sums_bytes) {
+            // (the runtime's answer, capped by LDS handed out in units of 512 bytes, the kernel's own static LDS
+            // included: at 23296 dynamic bytes the runtime still says seven blocks and the launch runs like six)
             auto blocks_with = [&](size_t lds, int* per_cu) -> int {
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_wf_pipeline<false, false>, WF_BLOCK, lds));
+                const size_t unit = (lds + sizeof(WfShared) + 511) & ~(size_t)511;
+                if (s->wf_lds_per_cu > 0) *per_cu = std::min<int>(*per_cu, (int)(s->wf_lds_per_cu / unit));
                 return RT_OK;
             };
             const char*  top_env = getenv("RT_WF_TOP"); // bytes; 0 switches the copy off
             const size_t top_max = std::min<size_t>((size_t)s->n_knodes * 8, top_env ? (size_t)atoi(top_env) & ~(size_t)7 : 8192);
             const int    cap_hi = s->d.stk_cap, cap_lo = s->wf_cap_lo;
-            size_t       top_of[2] = {0, 0};
-            int          per_cu_of[2] = {0, 0};
-            for (int v = 0; v < 2; ++v) { // v = 0: every stack entry stays, v = 1: one gives way
-                const size_t stacks = (size_t)(v == 0 ? cap_hi : cap_lo) * WF_BLOCK * WF_STACK_ENTRY_BYTES;
-                int          rc2 = blocks_with(stacks + sums_bytes, &per_cu_of[v]);
-                if (rc2) return rc2;
-                for (size_t top = top_max; top > 0; top = top > 1024 ? ((top - 1) & ~(size_t)1023) : 0) {
+            // as many stack entries as keep every block resident that the fewest entries would ...
+            int per_cu_max = 0, rc2;
+            if ((rc2 = blocks_with((size_t)cap_lo * WF_BLOCK * WF_STACK_ENTRY_BYTES + sums_bytes, &per_cu_max))) return rc2;
+            int cap_fit = cap_lo;
+            for (int c = cap_hi; c > cap_lo; --c) {
+                int per_cu = 0;
+                if ((rc2 = blocks_with((size_t)c * WF_BLOCK * WF_STACK_ENTRY_BYTES + sums_bytes, &per_cu))) return rc2;
+                if (per_cu >= per_cu_max) {
+                    cap_fit = c;
+                    break;
+                }
+            }
+            // ... and what is left for the nodes, with those entries and with one less
+            size_t top_of[2] = {0, 0};
+            for (int v = 0; v < 2; ++v) {
+                const int c = cap_fit - v;
+                if (c < cap_lo) break;
+                const size_t stacks = (size_t)c * WF_BLOCK * WF_STACK_ENTRY_BYTES;
+                for (size_t top = top_max; top > 0; top = top > 256 ? ((top - 1) & ~(size_t)255) : 0) {
                     int per_cu = 0;
                     if ((rc2 = blocks_with(stacks + sums_bytes + top, &per_cu))) return rc2;
-                    if (per_cu >= per_cu_of[v]) {
+                    if (per_cu >= per_cu_max) {
                         top_of[v] = top;
                         break;
                     }
                 }
             }
-            const bool full = top_of[0] >= std::min<size_t>(top_max, 2048);
-            const int  v = (full || cap_lo == cap_hi || per_cu_of[1] < per_cu_of[0] || top_of[1] < std::min<size_t>(top_max, 2048)) ? 0 : 1;
-            s->wf_single_cap = v == 0 ? cap_hi : cap_lo;
+            const size_t want = std::min<size_t>(top_max, 1024); // (final.obj 4K MSAA4 with the pending counts in LDS: 4 entries + 1 KB 5.67 ms, 3 entries + 2 / 3 KB 5.69 / 5.71 ms)
+            const int    v = (top_of[0] >= want || cap_fit - 1 < cap_lo || top_of[1] < want) ? 0 : 1;
+            const int    per_cu_of[2] = {per_cu_max, per_cu_max};
+            s->wf_single_cap = cap_fit - v;
             s->wf_single_top = top_of[v];
             s->wf_single_lds = (size_t)s->wf_single_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + sums_bytes + s->wf_single_top;
             s->wf_single_grid = std::min(s->wf_grid_pipe, std::max(1, per_cu_of[v]) * s->wf_cus);
@@ -1836,6 +1860,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         // (k_wf_order_*); by index the first time, after a change of shape, and for launches of a few regions.
         A.order = nullptr, A.cost = nullptr;
         A.top_bytes = (unsigned)s->wf_single_top;
+        A.pend_bytes = (unsigned)pend_bytes;
         const bool feedback = s->wf_feedback && A.n_regions > pl.G;
         if (feedback) {
             if ((size_t)A.n_regions > s->wf_order_cap) {

@@ -539,6 +539,8 @@ __device__ __forceinline__ long long wf_fix(float v)
 // an atomic on HBM is a transaction with the memory fabric: with the sums in HBM they made up a
 // fifth of the launch's traffic); the multi-launch kernels in the workspace.
 typedef __attribute__((address_space(3))) long long* WfLdsSums; // typed as LDS: ds_add_u64, not a flat atomic
+typedef __attribute__((address_space(3))) unsigned char* WfLdsBytes;
+typedef __attribute__((address_space(3))) unsigned* WfLdsWords;
 template <class PTR>
 struct WfAccT {
     PTR      at;
@@ -627,6 +629,9 @@ struct WfRegion {
                          // records, kept per level parity): parity * cap + base
     int*      n_child;   // rays appended to the next level's queue
     int*      n_sh;      // shadow rays appended
+    WfLdsBytes pend_out; // k_wf_pipeline, where LDS has room: one byte per ray slot of the level being shaded - the count of
+                         // pending queries (bits 0-2) and the lights found occluded (bits 3-6) of the slot's record; null:
+                         // the word in the record in HBM
 };
 
 // ---------------------------------------------------------------------------
@@ -817,6 +822,7 @@ __device__ __forceinline__ void wf_shade_ray(const DScene& S, const PT& P, const
             *(float4*)rec = make_float4(C.x, C.y, C.z, wl);
             *(uint4*)(rec + 16) = make_uint4(sl, (unsigned)(ncast * per), 0u, 0u);
             *(float4*)rec_v = v4; // (a record with queries has lights: its stride holds at least these 16 bytes)
+            if (!SOFT && g.pend_out) g.pend_out[j] = (unsigned char)ncast; // (at most four lights there: three bits)
             if (SOFT) {
                 unsigned* rec_n = (unsigned*)(rec_v + L);
                 for (int x = 0; x < ((L + 3) >> 2); ++x) rec_n[x] = 0u;
@@ -842,14 +848,17 @@ __device__ __forceinline__ unsigned wf_peek(const unsigned* p)
 // zero knows every answer and finishes the light loop: raytracing.cpp:142-164 with the
 // queries answered.  rec: the hit's record; sample0: first sample of the hit's region.
 // An atomic on HBM is a transaction with the memory fabric on this hardware whatever scope it
-// asks for (36.7 M of them per 4K frame of final.obj, 1.2 GB written).  Tried instead and not
+// asks for (36.7 M of them per 4K frame of final.obj, 1.2 GB written) - which is why the count lives in a byte of
+// LDS instead wherever a region's records are few enough for it (`pend`: no refraction, at most four lights, hard
+// shadows; 5.1 -> 3.6 GB written per frame, 5.79 -> 5.70 ms), and why a hit with a single query has no count at all.  Tried instead and not
 // kept: one byte per light set by plain stores and a lane per record finishing the light loop in
 // the stage after (no atomics, but the records have left the L2 by then: 10.1 vs 9.7 ms, 14.4 vs
 // 13.8 GB); non-temporal loads and stores for the queue entries (10.4 ms, traffic unchanged);
 // colour sums and records as arrays of structures (atomics to three words of one line: 11.2 ms).
 template <bool SOFT, class PT, class ACC>
 __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, size_t slot, const ACC& acc,
-                                               unsigned acc0, int li, bool occluded, bool sole)
+                                               unsigned acc0, int li, bool occluded, bool sole,
+                                               WfLdsBytes pend = nullptr, unsigned j = 0)
 {
     const int      L = P.n_lights;
     unsigned char* rec = B.rec + slot * B.rec_stride;
@@ -864,7 +873,16 @@ __device__ __forceinline__ void wf_shadow_done(const PT& P, const WfBuffers& B, 
     const float*   rec_v = (const float*)(rec + sizeof(WfRecord));
     unsigned*      rec_n = (unsigned*)(rec_v + L);
     unsigned       bits = 0;
-    if (!SOFT) {
+    if (!SOFT && pend) {
+        // The count and the answers in a byte of LDS (four records to a word; a region belongs to one block): the
+        // query count drops by one and the light's bit is set in one add - the byte never reaches zero before its
+        // last answer and never 128, so nothing is borrowed from or carried into its neighbours.
+        const unsigned sh8 = 8u * (j & 3u);
+        const unsigned delta = ((occluded ? (8u << li) : 0u) - 1u) << sh8;
+        const unsigned old = (__hip_atomic_fetch_add((WfLdsWords)(pend + (j & ~3u)), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh8) & 0xffu;
+        if ((old & 7u) != 1u) return;
+        bits = ((old + (occluded ? (8u << li) : 0u)) >> 3) & 0xfu;
+    } else if (!SOFT) {
         unsigned delta = 0xffffffffu; // one query less pending
         if (occluded) {
             if (li < 24) delta += 1u << (8 + li);
@@ -1123,6 +1141,7 @@ k_wf_shade(DScene S, DParams P, WfBuffers B, int level, long long slot0, DCounte
     WfRegion<WfAcc> g;
     g.base = (size_t)r * B.R, g.sample0 = (size_t)r * B.S * P.msaa, g.slot_base = slot0 + (long long)r * B.S;
     g.lvl0 = (size_t)(level & 1) * B.cap + g.base, g.n_child = &s_child, g.n_sh = &s_sh;
+    g.pend_out = nullptr;
     g.acc.at = B.acc, g.acc.n = (unsigned)B.n_samples, g.acc0 = (unsigned)g.sample0;
     if (threadIdx.x == 0) s_child = 0, s_sh = 0;
     __syncthreads();
@@ -1225,6 +1244,7 @@ struct WfLaunch {
     const int* order; // regions in the order they are handed out (null: by index), see k_wf_order_place
     unsigned*  cost;  // per region: how long it took this time (null: not recorded)
     unsigned   top_bytes; // of the node array, from its start, that every block copies into LDS (0: none)
+    unsigned   pend_bytes; // LDS bytes per level parity for the records' pending counts, behind that copy (0: the counts stay in the records)
 };
 typedef const __attribute__((address_space(4))) WfLaunch* WfLaunchC;
 
@@ -1285,6 +1305,10 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
     stk.top = (WfLdsEntries)(s_mem + (size_t)S.stk_cap * WF_BLOCK * WF_STACK_ENTRY_BYTES + (size_t)B.S * msaa * 24); // after the sums
     stk.top_bytes = A->top_bytes;
     stk.top_pairs = __builtin_amdgcn_readfirstlane(A->top_bytes >= 16u ? A->top_bytes - 8u : 0u);
+    const unsigned   pend_bytes = A->pend_bytes;
+    const WfLdsBytes pend0 = (WfLdsBytes)stk.top + A->top_bytes; // two planes of pend_bytes: level parity 0, 1
+    g.pend_out = pend_bytes ? pend0 + (level & 1) * pend_bytes : (WfLdsBytes) nullptr;
+    const WfLdsBytes pend_in = pend_bytes ? pend0 + ((level + 1) & 1) * pend_bytes : (WfLdsBytes) nullptr;
     // (what is read from LDS is the same for every lane; said so, it lives in scalar registers and
     // not, as a vector register per value, in scratch during the walks)
     int n_first = B.S, n_sh = 0;
@@ -1420,7 +1444,8 @@ __device__ __forceinline__ void wf_stage(const int kind, const int level, const 
             }
 #endif
             wf_shadow_done<SOFT>(P, B, in0 + (__float_as_uint(ow.w) & WF_TAG_SLOT),
-                                 g.acc, g.acc0, li, got, (__float_as_uint(ow.w) & WF_TAG_SOLE) != 0u);
+                                 g.acc, g.acc0, li, got, (__float_as_uint(ow.w) & WF_TAG_SOLE) != 0u, pend_in,
+                                 __float_as_uint(ow.w) & WF_TAG_SLOT);
             WF_SC(7);
         }
     }
