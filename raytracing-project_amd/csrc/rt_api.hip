@@ -1760,7 +1760,7 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     // enough (no refraction: a ray slot per sample) and the lights are at most four: an LDS atomic per answer
     // instead of a transaction with the memory fabric.  They are part of what the block's other LDS contents leave.
     const long long R_plan = (long long)S * P.msaa * (s->refractive ? 16 : 1);
-    const size_t    pend_bytes = (single && P.soft_n == 0 && L <= 4 && R_plan <= 1024 && !getenv("RT_WF_NO_LDS_PENDING")) ? (size_t)((R_plan + 3) & ~3LL) : 0;
+    const size_t    pend_bytes = (single && P.soft_n == 0 && L <= 4 && R_plan <= (getenv("RT_WF_PEND_MAX") ? atoi(getenv("RT_WF_PEND_MAX")) : 1024) && !getenv("RT_WF_NO_LDS_PENDING")) ? (size_t)((R_plan + 3) & ~3LL) : 0;
     const size_t sums_bytes = (size_t)S * P.msaa * 24 + 2 * pend_bytes; // (kept as one figure: what has to fit beside the stacks)
     int          grid_single = s->wf_grid_pipe;
     if (single) {
@@ -1812,8 +1812,8 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
             s->wf_single_grid = std::min(s->wf_grid_pipe, std::max(1, per_cu_of[v]) * s->wf_cus);
             s->wf_single_sums = sums_bytes;
             if (s->cfg.kd_stats)
-                fprintf(stderr, "wavefront: single launch with %d stack entries and %zu B of nodes in LDS, %zu B per block, %d blocks per CU\n",
-                        s->wf_single_cap, s->wf_single_top, s->wf_single_lds, per_cu_of[v]);
+                fprintf(stderr, "wavefront: single launch with %d stack entries, %zu B of nodes and %zu B of pending counts in LDS, %zu B per block, %d blocks per CU\n",
+                        s->wf_single_cap, s->wf_single_top, 2 * pend_bytes, s->wf_single_lds, per_cu_of[v]);
         }
         grid_single = s->wf_single_grid;
     }

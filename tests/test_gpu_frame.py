@@ -603,6 +603,33 @@ def test_render_paths_agree(P, oracle, monkeypatch):
     assert a[3].rays_closest == c[3].rays_closest
 
 
+def test_pending_counts_in_lds_and_in_the_records_agree(P, monkeypatch):
+    """Where a region's records are few (no refraction, at most four lights, hard shadows) the single launch keeps
+    the count of a hit's pending shadow queries and the lights found occluded in a byte of LDS; otherwise, and in
+    the launch-per-stage path, in a word of the hit's record.  Same frame bit for bit either way - final.obj
+    with its three lights and redballs with its four take the LDS path by default."""
+    for scene in ("final", "redballs"):
+        hs, gs, m, lights = _host_gpu(P, scene)
+        assert len(lights) <= 4
+        W, H = 224, 128
+        corners = P.host.camera_corners(m, W, H)
+        frames = {}
+        for name, env in [("lds", {}), ("records", {"RT_WF_NO_LDS_PENDING": "1"}), ("multilaunch", {"RT_WF_MULTILAUNCH": "1"})]:
+            for k in ("RT_WF_MULTILAUNCH", "RT_WF_NO_LDS_PENDING"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            g2 = hs.to_gpu(0)                            # the launch structure is read when a scene is created
+            frames[name] = [g2.render(corners, lights, P.capi.default_params(W, H, msaa)) for msaa in (1, 4)]
+        for k in ("RT_WF_MULTILAUNCH", "RT_WF_NO_LDS_PENDING"):
+            monkeypatch.delenv(k, raising=False)
+        for other in ("records", "multilaunch"):
+            for a, b in zip(frames["lds"], frames[other]):
+                assert a[3].rays_shadow > 0 and a[3].rays_shadow == b[3].rays_shadow
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), (scene, other)
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+
+
 def test_region_order_from_the_last_frame_changes_nothing(P, monkeypatch):
     """From the second frame of a shape on, the single launch hands its regions out in the order of the
     durations the frame before measured (k_wf_order_*).  That is a hint about when a region runs, never about
