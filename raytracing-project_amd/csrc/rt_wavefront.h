@@ -280,7 +280,8 @@ __device__ __forceinline__ void wf_stk_top2(const WfStack& k, int sp, uint2& top
 // alone, fetched after the plane has decided (8 bytes per step instead of 16, the decision no longer hidden
 // behind the load): 6.10 against 6.14 ms, no difference.  The exact record asked for together with the edge record,
 // so that the one candidate in four that goes on does not wait for a second load: 6.58 against 5.98 ms - three
-// more loads per candidate cost more than the wait they save.  Accordingly: the edge records in packed
+// more loads per candidate cost more than the wait they save.  With 4 GB less traffic per frame behind it (5.71 ms)
+// the launch answers to vector instructions again: eight / sixteen independent ones more per node step cost 4.4 / 6.5 %.  Accordingly: the edge records in packed
 // pairs (-2.4 % vector instructions) and edge records of two loads instead of three (unscaled gradients with one
 // error bound per scene) changed no frame time, the latter lost 7 % on fin.obj, whose triangles differ most in size.
 #ifdef WF_DIAG
