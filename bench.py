@@ -73,7 +73,7 @@ def cpu_share():
 def cpu_baseline(corners, lights):
     """The oracle (CPU restatement of the reference) on a bounded sample of the same frame,
     by the reference's own protocol (key 'R', main.cpp:261-267: mean of 5 runs) after one
-    warm-up run, at the two thread counts the survey names: the reference's policy
+    warm-up run, at two thread counts: the reference's policy
     min(16, hardware threads - 1) (config.h.dist:23, main.cpp:331) and every thread we may
     use.  The sample is 6 bands of rows spread over the image; the per-frame figure is
     extrapolated from it.  Checker code used as a reported baseline, never as the product."""
@@ -176,7 +176,8 @@ def frame_parts_in_flight(pkg, hs, corners, lights, dev_index, parts=8, frames=3
 
 
 def executed_flop(st, n_lights):
-    """The survey's weights on the work a launch really executed (its own counters)."""
+    """The flop weights of the frame figure F (45 per ray/triangle test, 40 per node step, 30 per shaded hit, 60 per
+    hit and light, 25 per child ray) on the work a launch really executed (its own counters)."""
     return (45 * st.tri_tests + 40 * st.node_visits + 30 * st.shaded_hits
             + 60 * st.shaded_hits * n_lights + 25 * st.child_rays)
 
@@ -742,7 +743,7 @@ def main():
                         "algorithmic_gflop_per_launch": round(f_kernel / 1e9, 2),
                         "frac_reference_walk": round(
                             fc["flops_frame"] * frac0 / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                        "frac_reference_walk_note": "the reference's whole walk (F of the survey, 105 tests per ray "
+                        "frac_reference_walk_note": "the reference's whole walk (F = 45 T + 40 S + 30 H + 60 Hl + 25 C over its counters, 105 tests per ray "
                         "in its tree) priced at this launch's duration: a yardstick of the frame against the "
                         "reference's algorithm, above 1 once the launch is faster than a peak-rate machine running "
                         "that algorithm; the launch itself executes the work under 'executed'",
