@@ -1742,7 +1742,10 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
         S = per_block >= 512 ? 256 : (per_block >= 100 ? 128 : 64);
         // without MSAA a region of 64 slots is one wave of camera rays for a block of four
         // (1080p: redballs 3.03 -> 2.59 ms, refractionballs 3.59 -> 2.77 ms with 128)
-        if (P.msaa == 1) S = std::max(S, 128);
+        // - and 192 slots, three waves of them, serve frames of half a million pixels and more better still
+        // (1080p: redballs 1.34 / 1.24 / 1.21 ms with 128 / 192 / 256, refractionballs 1.57 / 1.43 / 1.35 ms, but
+        // fin.obj, whose longest regions end the launch, 1.33 / 1.36 / 1.52 ms)
+        if (P.msaa == 1) S = std::max(S, n_slots >= 500000 ? 192 : 128);
     }
     if (s->cfg.region > 0) S = s->cfg.region;
     S = std::max(64, std::min(4096, (S / 64) * 64));
