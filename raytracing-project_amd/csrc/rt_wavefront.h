@@ -1488,7 +1488,12 @@ __device__ __forceinline__ int wf_order_bin(unsigned c) // bin 0 holds the longe
 // the blocks), and matters if it would still be running near the end - if it takes `hot` times what is left by
 // then, or longer.  Everything else stays in index order behind them, in the last bin.  (Sorting all regions by
 // duration puts the expensive ones on the GPU at the same time, where they take longer than mixed with cheap
-// ones: lego 4K 3.75 ms by index, 4.0 ms sorted; final 4K: the tail gone and nearly as much lost before it.)
+// ones: lego 4K 3.75 ms by index, 4.0 ms sorted; final 4K: the tail gone and nearly as much lost before it.
+// Handing the regions that go first out in halves or quarters, to as many blocks, so that their chains of levels get
+// shorter: 1080p frames 10 to 70 % slower when every such region is cut (smaller regions fill a block's waves
+// worse, and most of these regions are not what the launch ends with); cut only where a handful of regions outlast
+// all others - at least 0.7 of the longest, at most a sixteenth of the blocks - fin.obj 1080p, whose eight regions
+// of 1.1 to 1.4 ms are its launch, 1.33 -> 1.22 ms, redballs 1.24 -> 1.28 ms, every 4K frame unchanged: not kept.)
 struct WfOrderRule {
     float left_per_region; // hot * (sum of the durations / blocks) / n
     int   n;
