@@ -630,6 +630,33 @@ def test_pending_counts_in_lds_and_in_the_records_agree(P, monkeypatch):
                 assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
 
 
+def test_where_stacks_and_nodes_live_changes_nothing(P, monkeypatch):
+    """The walk keeps the first entries of a thread's stack and a copy of the tree's first levels in LDS; the rest
+    of a stack lies in HBM, the rest of the tree is read through the vector L1.  How much of either is in LDS is
+    a matter of time only: two stack entries (everything deeper spilled), eight, and no copy of the tree at all
+    give the default's frame bit for bit."""
+    hs, gs, m, lights = _host_gpu(P, "final")
+    W, H = 256, 144
+    corners = P.host.camera_corners(m, W, H)
+    keys = ("RT_WF_STACK_LDS", "RT_WF_TOP")
+    frames = []
+    for env in ({}, {"RT_WF_STACK_LDS": "2"}, {"RT_WF_STACK_LDS": "8", "RT_WF_TOP": "0"}, {"RT_WF_TOP": "512"}):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g2 = hs.to_gpu(0)                                # both are read when a scene is set up for its first frame
+        frames.append(g2.render(corners, lights, P.capi.default_params(W, H, 4)))
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    a = frames[0]
+    assert a[3].rays_closest > 0 and a[3].rays_shadow > 0
+    for b in frames[1:]:
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+        assert a[3].rays_closest == b[3].rays_closest and a[3].rays_shadow == b[3].rays_shadow
+
+
 def test_region_order_from_the_last_frame_changes_nothing(P, monkeypatch):
     """From the second frame of a shape on, the single launch hands its regions out in the order of the
     durations the frame before measured (k_wf_order_*).  That is a hint about when a region runs, never about
