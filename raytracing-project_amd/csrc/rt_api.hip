@@ -953,7 +953,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         const char*  lt_env = getenv("RT_KD_LEAF");
         const char*  ci_env = getenv("RT_KD_CI");
         KdSplitParams prm;
-        prm.leaf_target = lt_env ? atoi(lt_env) : 12; // do not split leaves at or below this size (4 until the plane heads, two at a time, made a test far cheaper than a node step)
+        prm.leaf_target = lt_env ? atoi(lt_env) : 16; // do not split leaves at or below this size (4 until the plane heads, two at a time, made a test far cheaper than a node step; 12 -> 16: final.obj's tree 6741 -> 2999 nodes, its 4K frame -0.5 %, ball 800x800 -6 %, lego +1 %; 20 and more: slower)
         prm.c_trav = 1.0, prm.c_isect = ci_env ? atof(ci_env) : 3.0;
         const char* ce_env = getenv("RT_KD_EMPTY");
         prm.c_empty = ce_env ? atof(ce_env) : 1.0; // (0.8, the usual bonus for a plane with an empty side: 1.5 % slower - an empty leaf is not free here)
@@ -991,7 +991,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         // RT_KD_REFINE=0 switches it off.  Tried and not kept: candidate planes and counts from
         // the triangles clipped to the cell ("perfect splits": more empty-space cuts, the node
         // budget runs out, 12.3 vs 12.0 ms per 4K frame), building the whole tree this way
-        // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms), and dropping planes that only cut an empty
+        // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms; with the pipeline and the plane heads 6.56 vs 5.66 ms, and 25-40 % slower on the 1080p frames), and dropping planes that only cut an empty
         // slab off where the other child's subtree alone is cheaper by this cost model plus a cost per leaf
         // visit (a fifth of the leaf visits are to empty leaves): 0 to 21 of 3300 planes qualify for a
         // leaf-visit cost of 0 to 16 node steps, frame times unchanged.
