@@ -350,10 +350,14 @@ k_depth_normalize(float* depth, long long n, const float* __restrict__ denom_p, 
 // compiler takes 255 registers, spills, and the kernel is five times slower); red and green of a tap in the two
 // halves of packed multiplications and additions (the same separately rounded products and sums, four
 // instructions per tap instead of six: 0.46 against 0.40 ms for range, normalisation and blur of a 4K frame -
-// the extra moves into and out of the register pairs cost more than the two instructions saved); the LDS
-// neighbourhood as 12-byte pixels read with ds_read2_b32 + ds_read_b32 instead of one 16-byte read (0.402
-// against 0.398 ms: a quarter fewer LDS bytes change nothing, the kernel is bound by the issue of its
-// ~1 800 vector instructions per pixel, of which the 169 taps' separately rounded products and sums are 1 014).
+// the extra moves into and out of the register pairs cost more than the two instructions saved; the same with
+// the weights kept in register pairs and v_pk_mul_f32 naming the half it wants, no move left, 1 830 -> 1 500
+// instructions per pixel: 0.399 against 0.400 ms - a packed FP32 multiplication or addition issues no faster
+// here than the two plain ones it stands for); the LDS neighbourhood as 12-byte pixels read with ds_read2_b32 +
+// ds_read_b32 instead of one read of the 16-byte pixel's first 12 bytes (0.402 against 0.398 ms: a quarter
+// fewer LDS bytes change nothing).  The kernel is bound by the issue of its plain vector instructions, four
+// cycles each per wave, of which the 169 taps' separately rounded products and sums are 1 014; only 21 of the
+// 37 powers and divisions are ever computed (the others occur in no 13 x 13 kernel, the compiler drops them).
 #define DOF_TW 32
 #define DOF_TH 8
 #define DOF_BLOCK (DOF_TW * DOF_TH)
