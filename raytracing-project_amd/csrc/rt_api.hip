@@ -355,7 +355,7 @@ k_depth_normalize(float* depth, long long n, const float* __restrict__ denom_p, 
 // instructions per pixel: 0.399 against 0.400 ms - a packed FP32 multiplication or addition issues no faster
 // here than the two plain ones it stands for); the LDS neighbourhood as 12-byte pixels read with ds_read2_b32 +
 // ds_read_b32 instead of one read of the 16-byte pixel's first 12 bytes (0.402 against 0.398 ms: a quarter
-// fewer LDS bytes change nothing).  The kernel is bound by the issue of its plain vector instructions, four
+// fewer LDS bytes change nothing; both together: 0.406).  The kernel is bound by the issue of its plain vector instructions, four
 // cycles each per wave, of which the 169 taps' separately rounded products and sums are 1 014; only 21 of the
 // 37 powers and divisions are ever computed (the others occur in no 13 x 13 kernel, the compiler drops them).
 #define DOF_TW 32
