@@ -355,8 +355,12 @@ k_depth_normalize(float* depth, long long n, const float* __restrict__ denom_p, 
 // instructions per pixel: 0.399 against 0.400 ms - a packed FP32 multiplication or addition issues no faster
 // here than the two plain ones it stands for); the LDS neighbourhood as 12-byte pixels read with ds_read2_b32 +
 // ds_read_b32 instead of one read of the 16-byte pixel's first 12 bytes (0.402 against 0.398 ms: a quarter
-// fewer LDS bytes change nothing; both together: 0.406).  The kernel is bound by the issue of its plain vector instructions, four
-// cycles each per wave, of which the 169 taps' separately rounded products and sums are 1 014; only 21 of the
+// fewer LDS bytes change nothing; both together: 0.406; three colour planes read a dword at a time with
+// immediate offsets, a quarter fewer LDS cycles and no address arithmetic: 0.392 against 0.399).  By the issue
+// costs measured on this GPU (plain additions and multiplications 1 ns per wave and SIMD with several waves
+// resident, compares, selects, packed and transcendental operations 1.75 ns and more) the vector instructions
+// of a 4K frame's 504 waves per CU take 0.27 ms and their 170 LDS reads 0.30 ms of the CU's LDS pipe; the kernel
+// takes 0.335 ms and follows neither figure down by more than 2 %.  Of its 1 830 vector instructions the 169 taps' separately rounded products and sums are 1 014; only 21 of the
 // 37 powers and divisions are ever computed (the others occur in no 13 x 13 kernel, the compiler drops them).
 #define DOF_TW 32
 #define DOF_TH 8
