@@ -385,17 +385,18 @@ __device__ __forceinline__ bool wf_traverse(const DScene& S, const WfStack& stk,
             // products in registers but formed them again at every step)
             const float tplane = (__uint_as_float(nd.x) - oa) * ia;
             // origin side of the plane: below it iff (split - o) > 0 iff tplane and d (hence 1/d) agree in sign
-            const bool below = (tplane > 0.0f) == (ia > 0.0f);
-            unsigned   sel = below ? 0u : 8u; // the child the walk goes on with, as its place in the pair: the near one ...
-            if (tplane > 0.0f && tplane <= tmax_e) {
-                if (tplane < tmin_e) sel ^= 8u; // ... the far one alone, if the plane lies before the cell's stretch of the ray
-                else {                          // ... or both: the far one waits on the stack
-                    wf_stk_put(stk, sp, (int)(left + (sel ^ 8u)), tplane);
-                    ++sp;
-                    tmax_e = tplane * (1.0f + RT_TRAV_EPS);
-                }
+            const bool pos = tplane > 0.0f, below = pos == (ia > 0.0f);
+            const bool in = pos && tplane <= tmax_e, near = tplane < tmin_e; // the plane is crossed before the cell ends / before it begins
+            // the child the walk goes on with, as its place in the pair: the near one, or the far one alone if the
+            // plane lies before the cell's stretch of the ray ...
+            const bool     first = below != (in && near);
+            const unsigned sel = first ? 0u : 8u;
+            if (in && !near) { // ... or both: the far one waits on the stack
+                wf_stk_put(stk, sp, (int)(left + (sel ^ 8u)), tplane);
+                ++sp;
+                tmax_e = tplane * (1.0f + RT_TRAV_EPS);
             }
-            nd = sel == 0u ? c0 : c1;
+            nd = first ? c0 : c1;
             if (COUNT) ++n_nodes;
         }
         const int cnt = (int)(nd.y & 0x3fffffffu);
