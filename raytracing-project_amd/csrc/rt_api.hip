@@ -360,8 +360,9 @@ k_depth_normalize(float* depth, long long n, const float* __restrict__ denom_p, 
 // costs measured on this GPU (plain additions and multiplications 1 ns per wave and SIMD with several waves
 // resident, compares, selects, packed and transcendental operations 1.75 ns and more) the vector instructions
 // of a 4K frame's 504 waves per CU take 0.27 ms and their 170 LDS reads 0.30 ms of the CU's LDS pipe; the kernel
-// takes 0.335 ms and follows neither figure down by more than 2 %.  Of its 1 830 vector instructions the 169 taps' separately rounded products and sums are 1 014; only 21 of the
-// 37 powers and divisions are ever computed (the others occur in no 13 x 13 kernel, the compiler drops them).
+// takes 0.335 ms and follows neither figure down by more than 2 %.  Of its 1 830 vector instructions the 169
+// taps' separately rounded products and sums are 1 014; only 21 of the 37 powers and divisions are ever computed
+// (the others occur in no 13 x 13 kernel, the compiler drops them).
 #define DOF_TW 32
 #define DOF_TH 8
 #define DOF_BLOCK (DOF_TW * DOF_TH)
@@ -539,7 +540,8 @@ struct RtScene {
     uint64_t   wf_order_key = 0;
     size_t     wf_order_cap = 0;
     bool       wf_feedback = true;                      // RT_WF_FEEDBACK=0: regions by index, always
-    float      wf_hot = 0.3f;                           // a region that takes this share of what is left of the launch when its turn comes, or more, goes first (RT_WF_HOT)
+    // a region that takes this share of what is left of the launch when its turn comes, or more, goes first (RT_WF_HOT)
+    float      wf_hot = 0.3f;
     size_t     wf_single_lds = 0;                       // last LDS size the single launch was sized for, and
     int        wf_single_grid = 0;                      // the blocks that stay resident with it
     void*      d_stk_spill = nullptr; // deep traversal stack entries of the wavefront kernels
@@ -961,7 +963,10 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         const char*  lt_env = getenv("RT_KD_LEAF");
         const char*  ci_env = getenv("RT_KD_CI");
         KdSplitParams prm;
-        prm.leaf_target = lt_env ? atoi(lt_env) : 16; // do not split leaves at or below this size (4 until the plane heads, two at a time, made a test far cheaper than a node step; 12 -> 16: final.obj's tree 6741 -> 2999 nodes, its 4K frame -0.5 %, ball 800x800 -6 %, lego +1 %; 20 and more: slower)
+        // Leaves at or below this size are not split (4 until the plane heads, two at a time, made a test far cheaper
+        // than a node step; 12 -> 16: final.obj's tree 6741 -> 2999 nodes, its 4K frame -0.5 %, ball 800x800 -6 %,
+        // lego +1 %; 20 and more: slower).
+        prm.leaf_target = lt_env ? atoi(lt_env) : 16;
         prm.c_trav = 1.0, prm.c_isect = ci_env ? atof(ci_env) : 3.0;
         const char* ce_env = getenv("RT_KD_EMPTY");
         prm.c_empty = ce_env ? atof(ce_env) : 1.0; // (0.8, the usual bonus for a plane with an empty side: 1.5 % slower - an empty leaf is not free here)
@@ -999,7 +1004,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** ou
         // RT_KD_REFINE=0 switches it off.  Tried and not kept: candidate planes and counts from
         // the triangles clipped to the cell ("perfect splits": more empty-space cuts, the node
         // budget runs out, 12.3 vs 12.0 ms per 4K frame), building the whole tree this way
-        // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms; with the pipeline and the plane heads 6.56 vs 5.66 ms, and 25-40 % slower on the 1080p frames), and dropping planes that only cut an empty
+        // from one root (RT_KD_REBUILD=1: 14.6 vs 13.3 ms; with the pipeline and the plane heads 6.56 vs 5.66 ms, and
+        // 25-40 % slower on the 1080p frames), and dropping planes that only cut an empty
         // slab off where the other child's subtree alone is cheaper by this cost model plus a cost per leaf
         // visit (a fifth of the leaf visits are to empty leaves): 0 to 21 of 3300 planes qualify for a
         // leaf-visit cost of 0 to 16 node steps, frame times unchanged.
@@ -1777,7 +1783,9 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
     // enough (no refraction: a ray slot per sample) and the lights are at most four: an LDS atomic per answer
     // instead of a transaction with the memory fabric.  They are part of what the block's other LDS contents leave.
     const long long R_plan = (long long)S * P.msaa * (s->refractive ? 16 : 1);
-    const size_t    pend_bytes = (single && P.soft_n == 0 && L <= 4 && R_plan <= (getenv("RT_WF_PEND_MAX") ? atoi(getenv("RT_WF_PEND_MAX")) : 1024) && !getenv("RT_WF_NO_LDS_PENDING")) ? (size_t)((R_plan + 3) & ~3LL) : 0;
+    const long long pend_max = getenv("RT_WF_PEND_MAX") ? atoi(getenv("RT_WF_PEND_MAX")) : 1024;
+    const bool      pend_lds = single && P.soft_n == 0 && L <= 4 && R_plan <= pend_max && !getenv("RT_WF_NO_LDS_PENDING");
+    const size_t    pend_bytes = pend_lds ? (size_t)((R_plan + 3) & ~3LL) : 0;
     const size_t sums_bytes = (size_t)S * P.msaa * 24 + 2 * pend_bytes; // (kept as one figure: what has to fit beside the stacks)
     int          grid_single = s->wf_grid_pipe;
     if (single) {
@@ -1820,7 +1828,8 @@ static int render_wavefront(RtScene* s, const DParams& P, long long n_slots, flo
                     }
                 }
             }
-            const size_t want = std::min<size_t>(top_max, 1024); // (final.obj 4K MSAA4 with the pending counts in LDS: 4 entries + 1 KB 5.67 ms, 3 entries + 2 / 3 KB 5.69 / 5.71 ms)
+            // (final.obj 4K MSAA4 with the pending counts in LDS: 4 entries + 1 KB 5.67 ms, 3 entries + 2 / 3 KB 5.69 / 5.71 ms)
+            const size_t want = std::min<size_t>(top_max, 1024);
             const int    v = (top_of[0] >= want || cap_fit - 1 < cap_lo || top_of[1] < want) ? 0 : 1;
             const int    per_cu_of[2] = {per_cu_max, per_cu_max};
             s->wf_single_cap = cap_fit - v;
