@@ -1494,7 +1494,11 @@ __device__ __forceinline__ int wf_order_bin(unsigned c) // bin 0 holds the longe
 // shorter: 1080p frames 10 to 70 % slower when every such region is cut (smaller regions fill a block's waves
 // worse, and most of these regions are not what the launch ends with); cut only where a handful of regions outlast
 // all others - at least 0.7 of the longest, at most a sixteenth of the blocks - fin.obj 1080p, whose eight regions
-// of 1.1 to 1.4 ms are its launch, 1.33 -> 1.22 ms, redballs 1.24 -> 1.28 ms, every 4K frame unchanged: not kept.)
+// of 1.1 to 1.4 ms are its launch, 1.33 -> 1.22 ms, redballs 1.24 -> 1.28 ms, every 4K frame unchanged: not kept.
+// A fixed order for the first frame of a view, when no durations exist yet - a stride of 0.618 n through the regions,
+// or back to front - helps where the expensive regions happen to lie late in index order and hurts elsewhere:
+// against by index, the stride lego 3.54 -> 3.34, fin 1.40 -> 1.30, redballs 1.50 -> 1.63, final 5.87 -> 6.08 ms;
+// back to front final 5.61, refractionballs 1.65 -> 1.72 ms: no rule without knowing the scene, by index stays.)
 struct WfOrderRule {
     float left_per_region; // hot * (sum of the durations / blocks) / n
     int   n;
